@@ -1,0 +1,276 @@
+"""Pins oracle/bn254_oracle.c: (1) the reference tests' own known-answer vectors, (2) fixtures generated from the
+reference itself (tools/gen_golden.py -> oracle/_ref), (3) property checks from the reference's test strategy
+(test/test_wnaf.cpp, test/test_fr.cpp:239-294, test/test_polynomial_arithmetic.cpp:31-128)."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FQ, FR, FR_MODULUS, NTT_KINDS, from_int, to_int
+from tests.util import CONST_SEED, NTT_SEED, SCALAR_SEED, SRS_SEED, limbs, noncanonical, sha
+
+F = {"fq": FQ, "fr": FR}
+
+
+def test_reference_field_kats(oracle, golden):
+    kats = golden("reference_kats.json")
+    for fname in ("fq", "fr"):
+        for k in kats[fname]:
+            a = limbs(k["a"])
+            fn = getattr(oracle, k["op"])
+            got = fn(F[fname], a, limbs(k["b"])) if "b" in k else fn(F[fname], a)
+            assert np.array_equal(got, limbs(k["expected"])), k["cite"]
+
+
+def _mont_pt(oracle, d, keys):
+    return np.concatenate([oracle.to_mont(FQ, limbs(d[c])) for c in keys])
+
+
+def _proj_eq(oracle, a, b):
+    na, nb = oracle.g1_normalize(a), oracle.g1_normalize(b)
+    return np.array_equal(na, nb)
+
+
+def test_reference_g1_kats(oracle, golden):
+    for k in golden("reference_kats.json")["g1"]:
+        if k["op"] == "mixed_add":
+            got = oracle.g1_mixed_add(_mont_pt(oracle, k["a"], "xyz"), _mont_pt(oracle, k["b"], "xy"))
+        elif k["op"] == "dbl3":
+            got = _mont_pt(oracle, k["a"], "xyz")
+            for _ in range(3):
+                got = oracle.g1_dbl(got)
+        elif k["op"] == "add":
+            got = oracle.g1_add(_mont_pt(oracle, k["a"], "xyz"), _mont_pt(oracle, k["b"], "xyz"))
+        else:
+            s = oracle.to_mont(FR, limbs(k["scalar"]))
+            got = oracle.g1_scalar_mul(oracle.g1_one_affine(), s)
+            want = np.concatenate([_mont_pt(oracle, k["expected"], "xy"), oracle.const(FQ, "one")])
+            assert np.array_equal(got, want), k["cite"]
+            continue
+        assert _proj_eq(oracle, got, _mont_pt(oracle, k["expected"], "xyz")), k["cite"]
+
+
+def test_golden_field_ops(oracle, golden):
+    for c in golden("field_ops.json")["cases"]:
+        f, a, b = F[c["field"]], limbs(c["a"]), limbs(c["b"])
+        for op in ("mul", "mul_coarse", "add", "sub", "add_coarse", "sub_coarse"):
+            if op in c:
+                assert np.array_equal(getattr(oracle, op)(f, a, b), limbs(c[op])), (c["field"], op)
+        for op in ("sqr", "sqr_coarse", "neg", "to_mont", "from_mont", "reduce_once", "invert"):
+            if op in c:
+                assert np.array_equal(getattr(oracle, op)(f, a), limbs(c[op])), (c["field"], op)
+
+
+def test_golden_endo_wnaf(oracle, golden):
+    lam = oracle.const(FR, "beta")
+    for c in golden("endo_wnaf.json")["cases"]:
+        k = limbs(c["k"])
+        k1, k2 = oracle.split_endo(k)
+        assert np.array_equal(k1, limbs(c["k1"])) and np.array_equal(k2, limbs(c["k2"]))
+        # k == k1 - lambda*k2 (test_fr.cpp:239-294)
+        k1m = oracle.to_mont(FR, np.concatenate([k1, np.zeros(2, dtype=np.uint64)]))
+        k2m = oracle.to_mont(FR, np.concatenate([k2, np.zeros(2, dtype=np.uint64)]))
+        back = oracle.from_mont(FR, oracle.sub(FR, k1m, oracle.mul(FR, k2m, lam)))
+        assert to_int(back) == to_int(k) % FR_MODULUS
+        for name, w in c["wnaf"].items():
+            half, bits = name.split("_w")
+            digits, skew = oracle.fixed_wnaf(k1 if half == "k1" else k2, int(bits))
+            assert [int(d) for d in digits] == w["digits"] and skew == w["skew"], name
+
+
+def test_wnaf_roundtrip(oracle):
+    """test_wnaf.cpp:11-131 recover_fixed_wnaf, restated"""
+    rng = np.random.default_rng(7)
+    cases = [(0, 0), (1, 0), (0, 1)] + [(int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2)), int(rng.integers(0, 1 << 63))) for _ in range(50)]
+    for lo, hi in cases:
+        for w in (3, 5, 11, 16):
+            digits, skew = oracle.fixed_wnaf(np.array([lo, hi], dtype=np.uint64), w)
+            entries = len(digits)
+            v = 0
+            for i, e in enumerate(digits):
+                d = ((int(e) & 0x0FFFFFFF) << 1) + 1
+                v += (-d if int(e) >> 31 else d) << (w * (entries - 1 - i))
+            assert v - skew == lo + (hi << 64)
+
+
+def test_golden_g1_ops(oracle, golden):
+    one = oracle.g1_one_affine()
+    for c in golden("g1_ops.json")["cases"]:
+        acc = limbs(c["acc"])
+        q = limbs(c["scalar_mul_G"])
+        assert np.array_equal(oracle.g1_scalar_mul(one, limbs(c["scalar"])), q)
+        m = oracle.g1_mixed_add(acc, q[:8])
+        assert np.array_equal(m, limbs(c["mixed_add"]))
+        a = oracle.g1_add(m, acc)
+        assert np.array_equal(a, limbs(c["add"]))
+        d = oracle.g1_dbl(a)
+        assert np.array_equal(d, limbs(c["dbl"]))
+        assert np.array_equal(oracle.g1_normalize(d), limbs(c["normalize"]))
+
+
+def test_g1_exception_cases(oracle):
+    """test_g1.cpp:124-241: P+(-P)=inf, P+P=dbl, inf+P=P"""
+    one = oracle.g1_one_affine()
+    s = oracle.random_scalars(99, 1)[0]
+    p = oracle.g1_scalar_mul(one, s)
+    neg = p.copy()
+    neg[4:8] = oracle.neg(FQ, p[4:8])
+    assert oracle.is_infinity(oracle.g1_add(p, neg))
+    assert oracle.is_infinity(oracle.g1_mixed_add(p, neg[:8]))
+    assert np.array_equal(oracle.g1_normalize(oracle.g1_add(p, p)), oracle.g1_normalize(oracle.g1_dbl(p)))
+    assert np.array_equal(oracle.g1_normalize(oracle.g1_mixed_add(p, p[:8])), oracle.g1_normalize(oracle.g1_dbl(p)))
+    inf = np.zeros(12, dtype=np.uint64)
+    inf[7] = np.uint64(1 << 63)
+    assert np.array_equal(oracle.g1_add(inf, p), p) and np.array_equal(oracle.g1_add(p, inf), p)
+    assert np.array_equal(oracle.g1_mixed_add(inf, p[:8])[:8], p[:8])
+    assert oracle.is_infinity(oracle.g1_dbl(inf))
+
+
+@pytest.fixture(scope="module")
+def msm_inputs(oracle, golden):
+    g = golden("msm.json")
+    x = limbs(g["srs_secret_mont"])
+    assert np.array_equal(x, oracle.random_scalars(SRS_SEED, 1)[0])
+    n = 4096
+    srs = oracle.make_srs(x, n)
+    for i, v in g["srs_samples"].items():
+        assert np.array_equal(srs[int(i)], limbs(v))
+    table = oracle.point_table(srs)
+    assert sha(table[:8192]) == g["table_digest_4096"]
+    scalars = oracle.random_scalars(SCALAR_SEED, n)
+    return g, srs, table, scalars
+
+
+def test_bucket_width_table(oracle):
+    for n, c in ((1 << 20, 15), (1 << 16, 12), (131072, 15), (8192, 10), (10000, 10), (1, 1), (0, 1), (2, 2), (99999, 12), (100000, 15)):
+        assert oracle.optimal_bucket_width(n) == c
+
+
+def test_golden_msm(oracle, msm_inputs):
+    g, srs, table, scalars = msm_inputs
+    done = 0
+    for c in g["cases"]:
+        n = c["n"]
+        if n > 4096 or "x" not in c or "scalars" in c or "points" in c:
+            continue
+        out = oracle.msm_affine(scalars, table, n, c["forced_bucket_width"])
+        assert np.array_equal(out[0:4], limbs(c["x"])) and np.array_equal(out[4:8], limbs(c["y"])), c
+        done += 1
+    assert done >= 8
+
+
+def test_golden_msm_edge_cases(oracle, msm_inputs):
+    from oracle.pyoracle import aligned_copy
+    g, srs, table, scalars = msm_inputs
+    seen = 0
+    for c in g["cases"]:
+        if c.get("scalars") == "even-index scalars zero":
+            zs = scalars[:64].copy()
+            zs[::2] = 0
+            out = oracle.msm_affine(aligned_copy(zs), table, 64)
+        elif c.get("scalars") == "all zero":
+            out = oracle.pippenger(aligned_copy(np.zeros((16, 4), dtype=np.uint64)), table, 16)
+            assert oracle.is_infinity(out) == c["infinity"]
+            seen += 1
+            continue
+        elif c["n"] == 0:
+            assert oracle.is_infinity(oracle.pippenger(scalars, table, 0)) == c["infinity"]
+            seen += 1
+            continue
+        elif "points" in c:
+            same_t = oracle.point_table(aligned_copy(np.tile(srs[5], (32, 1))))
+            sc = aligned_copy(np.tile(oracle.const(FR, "one"), (32, 1))) if c.get("scalars") == "all one" else scalars
+            out = oracle.msm_affine(sc, same_t, 32)
+        else:
+            continue
+        assert np.array_equal(out[0:4], limbs(c["x"])) and np.array_equal(out[4:8], limbs(c["y"])), c
+        seen += 1
+    assert seen == 5
+
+
+def test_golden_batched_msm(oracle, msm_inputs):
+    """batched_scalar_multiplications (scalar_multiplication.cpp:650-772): normalised outputs, any thread split"""
+    import ctypes as C
+    from oracle.pyoracle import aligned_copy, ptr
+    g, srs, table, scalars = msm_inputs
+    big = oracle.random_scalars(SCALAR_SEED, 3 * 4096)
+
+    class Job(C.Structure):
+        _fields_ = [("points", C.POINTER(C.c_uint64)), ("scalars", C.POINTER(C.c_uint64)), ("n", C.c_size_t), ("out", C.c_uint64 * 12)]
+    for threads in (1, 8):
+        keep = [aligned_copy(big[o:o + 4096]) for o in (0, 4096, 8192)]
+        jobs = (Job * 3)()
+        for j, s in zip(jobs, keep):
+            j.points, j.scalars, j.n = ptr(table), ptr(s), 4096
+        assert oracle.lib.orc_batched_msm(jobs, C.c_size_t(3), C.c_size_t(threads)) == 0
+        for j, want in zip(jobs, g["batched_3x4096"]):
+            got = np.array(list(j.out), dtype=np.uint64)
+            assert np.array_equal(got[0:4], limbs(want["x"])) and np.array_equal(got[4:8], limbs(want["y"]))
+            assert np.array_equal(got[8:12], limbs(want["z"]))
+
+
+def test_msm_vs_naive(oracle, msm_inputs):
+    """test_scalar_multiplication.cpp:72-104 shape: pippenger == sum of individual scalar multiplications"""
+    g, srs, table, scalars = msm_inputs
+    n = 40
+    acc = np.zeros(12, dtype=np.uint64)
+    acc[7] = np.uint64(1 << 63)
+    for i in range(n):
+        acc = oracle.g1_add(acc, oracle.g1_scalar_mul(srs[i], scalars[i]))
+    assert np.array_equal(oracle.g1_normalize(acc), oracle.msm_affine(scalars, table, n))
+
+
+def test_golden_ntt_small(oracle, golden):
+    g = golden("ntt.json")
+    const = limbs(g["constant"])
+    assert np.array_equal(const, oracle.random_scalars(CONST_SEED, 1)[0])
+    for c in g["small"]:
+        co = limbs(c["input"]).reshape(-1, 4)
+        assert np.array_equal(co, noncanonical(oracle.random_scalars(NTT_SEED, c["n"]), FR_MODULUS))
+        out = oracle.ntt(co, c["kind"], const)
+        assert np.array_equal(out.reshape(-1), limbs(c["output"])), (c["n"], c["kind"])
+
+
+def test_golden_ntt_digests(oracle, golden):
+    g = golden("ntt.json")
+    const = limbs(g["constant"])
+    for c in g["large"]:
+        n = c["n"]
+        if n > 4096:
+            continue
+        co = noncanonical(oracle.random_scalars(NTT_SEED, n), FR_MODULUS)
+        out = oracle.ntt(co, c["kind"], const)
+        assert sha(out) == c["sha256"], (n, c["kind"])
+        for i, v in c["samples"].items():
+            assert np.array_equal(out[int(i)], limbs(v))
+
+
+def test_golden_ntt_2_16_fft(oracle, golden):
+    g = golden("ntt.json")
+    c = [c for c in g["large"] if c["n"] == 65536 and c["kind"] == "coset_fft"][0]
+    co = noncanonical(oracle.random_scalars(NTT_SEED, 65536), FR_MODULUS)
+    assert sha(oracle.ntt(co, "coset_fft")) == c["sha256"]
+
+
+def test_fft_matches_direct_evaluation(oracle):
+    """test_polynomial_arithmetic.cpp:31-56"""
+    n = 16
+    poly = oracle.random_scalars(4242, n)
+    out = oracle.ntt(poly, "fft")
+    root = oracle.root_of_unity(4)
+    w = oracle.const(FR, "one")
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.evaluate(poly, w))
+        w = oracle.mul(FR, w, root)
+
+
+def test_fft_roundtrips(oracle):
+    """test_polynomial_arithmetic.cpp:58-128"""
+    for n in (2, 256, 1024):
+        poly = oracle.random_scalars(31337 + n, n)
+        canon = np.stack([oracle.reduce_once(FR, p) for p in poly])
+        assert np.array_equal(oracle.ntt(oracle.ntt(poly, "fft"), "ifft"), canon)
+        assert np.array_equal(oracle.ntt(oracle.ntt(poly, "coset_fft"), "coset_ifft"), canon)
+
+
+def test_ntt_kinds_complete():
+    assert set(NTT_KINDS) == {"fft", "ifft", "coset_fft", "coset_ifft", "fft_with_constant", "ifft_with_constant",
+                              "coset_fft_with_constant"}
