@@ -1,0 +1,174 @@
+"""ctypes mirror of the reference's operator interface for the hot path, over the C ABI of libbbgpu.so.
+
+Names follow the reference: ``pippenger`` / ``batched_scalar_multiplications``
+(src/barretenberg/curves/bn254/scalar_multiplication.hpp:60-96) and ``fft`` / ``ifft`` / ``coset_fft`` / ``coset_ifft`` /
+``fft_with_constant`` / ``ifft_with_constant`` / ``coset_fft_with_constant``
+(src/barretenberg/polynomials/polynomial_arithmetic.hpp:27-41).  Arrays are numpy uint64 in the reference's memory
+layout: field element (4,), affine point (8,), Jacobian (12,).  Device-resident variants take raw device pointers
+(e.g. ``torch.Tensor.data_ptr()``); torch is plumbing only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+u64p = C.POINTER(C.c_uint64)
+
+NTT_KINDS = {
+    "fft": 0,
+    "ifft": 1,
+    "coset_fft": 2,
+    "coset_ifft": 3,
+    "fft_with_constant": 4,
+    "ifft_with_constant": 5,
+    "coset_fft_with_constant": 6,
+}
+
+C_ABI_SYMBOLS = [
+    "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
+    "bbgpu_ntt_device", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_msm_g1",
+    "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_g1_sum", "bbgpu_last_timing",
+    "bbgpu_set_timing",
+]
+
+
+class BbGpuError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(HERE, "libbbgpu.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of libbbgpu.so, in-tree (cross-compiles without a GPU)."""
+    src = os.path.join(HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-C", src, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", src, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+class MsmJob(C.Structure):
+    """layout of scalar_multiplication::multiplication_state (scalar_multiplication.hpp:88-94)"""
+    _fields_ = [("points", u64p), ("scalars", u64p), ("num_elements", C.c_size_t), ("_pad", C.c_uint64),
+                ("output", C.c_uint64 * 12)]
+
+
+def _ptr(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need C-contiguous uint64"
+    return a.ctypes.data_as(u64p)
+
+
+class BbGpu:
+    def __init__(self, device=0, init=True):
+        path = library_path()
+        if not os.path.exists(path):
+            raise BbGpuError("libbbgpu.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = self.lib = C.CDLL(path)
+        L.bbgpu_last_error.restype = C.c_char_p
+        L.bbgpu_version.restype = C.c_char_p
+        L.bbgpu_ntt.argtypes = [u64p, C.c_size_t, C.c_int, u64p]
+        L.bbgpu_ntt_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, u64p, C.c_void_p]
+        L.bbgpu_srs_register.argtypes = [u64p, C.c_size_t]
+        L.bbgpu_srs_generate.argtypes = [u64p, C.c_size_t, u64p]
+        L.bbgpu_msm_g1.argtypes = [u64p, u64p, C.c_size_t, u64p]
+        L.bbgpu_msm_g1_batch.argtypes = [C.POINTER(MsmJob), C.c_size_t]
+        L.bbgpu_msm_num_windows.argtypes = [C.c_size_t]
+        L.bbgpu_msm_g1_device.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
+        L.bbgpu_g1_sum.argtypes = [u64p, C.c_size_t, u64p]
+        L.bbgpu_last_timing.argtypes = [C.POINTER(C.c_float), C.c_int]
+        self.device = device
+        if init:
+            self._chk(L.bbgpu_init(device))
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise BbGpuError("bbgpu error %d: %s" % (rc, self.lib.bbgpu_last_error().decode()))
+        return rc
+
+    def version(self):
+        return self.lib.bbgpu_version().decode()
+
+    def device_count(self):
+        return int(self.lib.bbgpu_device_count())
+
+    def shutdown(self):
+        self.lib.bbgpu_shutdown()
+
+    # ---- polynomial_arithmetic ------------------------------------------------------------------------------------
+    def ntt(self, coeffs, kind, constant=None):
+        """in place on a (n, 4) uint64 host array"""
+        kind = NTT_KINDS[kind] if isinstance(kind, str) else kind
+        cp = _ptr(np.ascontiguousarray(constant, dtype=np.uint64)) if constant is not None else None
+        self._chk(self.lib.bbgpu_ntt(_ptr(coeffs), coeffs.shape[0], kind, cp))
+        return coeffs
+
+    def fft(self, coeffs): return self.ntt(coeffs, "fft")
+    def ifft(self, coeffs): return self.ntt(coeffs, "ifft")
+    def coset_fft(self, coeffs): return self.ntt(coeffs, "coset_fft")
+    def coset_ifft(self, coeffs): return self.ntt(coeffs, "coset_ifft")
+    def fft_with_constant(self, coeffs, value): return self.ntt(coeffs, "fft_with_constant", value)
+    def ifft_with_constant(self, coeffs, value): return self.ntt(coeffs, "ifft_with_constant", value)
+    def coset_fft_with_constant(self, coeffs, constant): return self.ntt(coeffs, "coset_fft_with_constant", constant)
+
+    def ntt_device(self, d_ptr, n, kind, constant=None, stream=None):
+        kind = NTT_KINDS[kind] if isinstance(kind, str) else kind
+        cp = _ptr(np.ascontiguousarray(constant, dtype=np.uint64)) if constant is not None else None
+        self._chk(self.lib.bbgpu_ntt_device(C.c_void_p(d_ptr), n, kind, cp, C.c_void_p(stream or 0)))
+
+    # ---- scalar_multiplication ------------------------------------------------------------------------------------
+    def srs_register(self, points_endo_table):
+        return self._chk(self.lib.bbgpu_srs_register(_ptr(points_endo_table), points_endo_table.shape[0] // 2))
+
+    def srs_generate(self, x_mont, n, want_host_table=False):
+        table = np.zeros((2 * n, 8), dtype=np.uint64) if want_host_table else None
+        h = self._chk(self.lib.bbgpu_srs_generate(_ptr(np.ascontiguousarray(x_mont, dtype=np.uint64)), n,
+                                                  _ptr(table) if want_host_table else None))
+        return (h, table) if want_host_table else h
+
+    def srs_release(self, handle):
+        self._chk(self.lib.bbgpu_srs_release(handle))
+
+    def pippenger(self, scalars, points_endo_table, n=None):
+        """returns the normalised g1::element (12,) -- or the infinity flag in y limb 3"""
+        n = scalars.shape[0] if n is None else n
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.lib.bbgpu_msm_g1(_ptr(scalars), _ptr(points_endo_table), n, _ptr(out)))
+        return out
+
+    def batched_scalar_multiplications(self, jobs):
+        """jobs: list of (points_endo_table, scalars, n); returns list of normalised outputs"""
+        arr = (MsmJob * len(jobs))()
+        for j, (pts, sc, n) in zip(arr, jobs):
+            j.points, j.scalars, j.num_elements = _ptr(pts), _ptr(sc), n
+        self._chk(self.lib.bbgpu_msm_g1_batch(arr, len(jobs)))
+        return [np.array(list(j.output), dtype=np.uint64) for j in arr]
+
+    def msm_num_windows(self, n):
+        return int(self.lib.bbgpu_msm_num_windows(n))
+
+    def msm_device(self, handle, d_scalars_ptr, n, offset=0, window_begin=0, window_end=None, stream=None):
+        if window_end is None:
+            window_end = self.msm_num_windows(n)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.lib.bbgpu_msm_g1_device(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,
+                                               _ptr(out), C.c_void_p(stream or 0)))
+        return out
+
+    def g1_sum(self, points12):
+        points12 = np.ascontiguousarray(points12, dtype=np.uint64).reshape(-1, 12)
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.lib.bbgpu_g1_sum(_ptr(points12), points12.shape[0], _ptr(out)))
+        return out
+
+    # ---- instrumentation ---------------------------------------------------------------------------------------------
+    def set_timing(self, on=True):
+        self.lib.bbgpu_set_timing(1 if on else 0)
+
+    def last_timing(self):
+        buf = (C.c_float * 8)()
+        k = self.lib.bbgpu_last_timing(buf, 8)
+        return [float(buf[i]) for i in range(k)]

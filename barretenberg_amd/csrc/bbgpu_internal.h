@@ -1,0 +1,38 @@
+// bbgpu_internal.h -- declarations shared by the HIP translation units and the C-ABI shim (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/bbgpu.h"
+
+namespace bbgpu {
+
+void set_error(const char* fmt, ...);
+
+// ntt.hip
+int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256, hipStream_t st);
+void ntt_release_tables();
+
+// msm.hip
+namespace host { struct Xyzz; }
+struct MsmTiming {
+    int count = 0;
+    float ms[8]; // [0] total device time, then digits, sort, accumulate, rows/cols folds, slices+collect
+};
+struct MsmWorkspace {
+    uint8_t* base = nullptr;
+    size_t cap = 0;
+    void* h_out = nullptr; // pinned
+    static size_t bytes_needed(size_t n, int c, int nw);
+    int ensure(size_t bytes);
+    void release();
+};
+int msm_choose_c(size_t n);
+int msm_num_windows(int c);
+int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, host::Xyzz* result,
+            hipStream_t st, MsmTiming* timing);
+int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st);
+int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);
+
+} // namespace bbgpu

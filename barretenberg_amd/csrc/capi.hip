@@ -1,0 +1,355 @@
+// capi.hip -- the C-ABI of libbbgpu.so (include/bbgpu.h): context, SRS registry, host<->device staging.
+// One process drives one GPU (bbgpu_init(device)); all entry points are serialised by one mutex, which also makes the
+// reference's concurrent pippenger() calls from an OpenMP region (scalar_multiplication.cpp:731-738) safe.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "bbgpu_internal.h"
+#include "host_g1.hpp"
+
+namespace bbgpu {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+struct SrsEntry {
+    const uint64_t* host_ptr; // may be null for device-generated tables
+    size_t n;
+    uint32_t* d_srs;
+    bool live;
+};
+
+struct Context {
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<SrsEntry> srs;
+    MsmWorkspace ws;
+    uint64_t* d_stage = nullptr; // scalars / coefficients staging
+    size_t stage_cap = 0;
+    uint64_t* d_scratch = nullptr; // NTT scratch
+    size_t scratch_cap = 0;
+    bool timing = false;
+    MsmTiming last;
+};
+
+std::recursive_mutex g_mu;
+Context g_ctx;
+
+#define CHK(x)                                                                                                         \
+    do {                                                                                                               \
+        hipError_t e_ = (x);                                                                                           \
+        if (e_ != hipSuccess) {                                                                                        \
+            set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));                                \
+            return BBGPU_ERR_HIP;                                                                                      \
+        }                                                                                                              \
+    } while (0)
+
+int ensure_init()
+{
+    if (g_ctx.ready) return BBGPU_OK;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
+        set_error("no HIP device available: libbbgpu has no CPU fallback");
+        return BBGPU_ERR_HIP;
+    }
+    CHK(hipSetDevice(g_ctx.device));
+    CHK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    g_ctx.ready = true;
+    return BBGPU_OK;
+}
+
+int grow(uint64_t** buf, size_t* cap, size_t bytes)
+{
+    if (bytes <= *cap) return BBGPU_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    CHK(hipMalloc((void**)buf, bytes));
+    *cap = bytes;
+    return BBGPU_OK;
+}
+
+// table lookup by host address: returns entry index and point offset, or -1
+int find_srs(const uint64_t* points, size_t n, size_t* offset)
+{
+    for (size_t i = 0; i < g_ctx.srs.size(); i++) {
+        const SrsEntry& e = g_ctx.srs[i];
+        if (!e.live || !e.host_ptr) continue;
+        const uint8_t* b = (const uint8_t*)e.host_ptr;
+        const uint8_t* p = (const uint8_t*)points;
+        if (p < b || p >= b + e.n * 128) continue;
+        const size_t d = (size_t)(p - b);
+        if (d % 128) continue;
+        if (d / 128 + n > e.n) continue;
+        *offset = d / 128;
+        return (int)i;
+    }
+    return -1;
+}
+
+int log2_exact(size_t n)
+{
+    if (n == 0 || (n & (n - 1))) return -1;
+    int l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12])
+{
+    if (n == 0) {
+        host::g1_to_normalised(host::g1_infinity(), out);
+        return BBGPU_OK;
+    }
+    if (!scalars || !points) {
+        set_error("null scalars/points");
+        return BBGPU_ERR_ARG;
+    }
+    size_t off = 0;
+    int idx = find_srs(points, n, &off);
+    if (idx < 0) {
+        uint32_t* d = nullptr;
+        int rc = srs_upload(points, n, &d, g_ctx.stream);
+        if (rc) return rc;
+        g_ctx.srs.push_back({ points, n, d, true });
+        idx = (int)g_ctx.srs.size() - 1;
+        off = 0;
+    }
+    int rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
+    if (rc) return rc;
+    CHK(hipMemcpyAsync(g_ctx.d_stage, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+    host::Xyzz res;
+    const int W = msm_num_windows(msm_choose_c(n));
+    rc = msm_run(g_ctx.ws, g_ctx.srs[idx].d_srs + off * 16, g_ctx.d_stage, n, 0, W, &res, g_ctx.stream, g_ctx.timing ? &g_ctx.last : nullptr);
+    if (rc) return rc;
+    host::g1_to_normalised(res, out);
+    return BBGPU_OK;
+}
+
+} // namespace
+} // namespace bbgpu
+
+using namespace bbgpu;
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* bbgpu_version(void) { return "bbgpu 0.1 (gfx950)"; }
+const char* bbgpu_last_error(void) { return g_err; }
+
+int bbgpu_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int bbgpu_init(int device)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (g_ctx.ready && g_ctx.device == device) return BBGPU_OK;
+    if (g_ctx.ready) {
+        set_error("already bound to device %d (one process per GPU)", g_ctx.device);
+        return BBGPU_ERR_STATE;
+    }
+    g_ctx.device = device;
+    return ensure_init();
+}
+
+void bbgpu_shutdown(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!g_ctx.ready) return;
+    (void)hipStreamSynchronize(g_ctx.stream);
+    for (auto& e : g_ctx.srs)
+        if (e.live && e.d_srs) (void)hipFree(e.d_srs);
+    g_ctx.srs.clear();
+    g_ctx.ws.release();
+    if (g_ctx.d_stage) (void)hipFree(g_ctx.d_stage);
+    if (g_ctx.d_scratch) (void)hipFree(g_ctx.d_scratch);
+    g_ctx.d_stage = g_ctx.d_scratch = nullptr;
+    g_ctx.stage_cap = g_ctx.scratch_cap = 0;
+    ntt_release_tables();
+    (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx.stream = nullptr;
+    g_ctx.ready = false;
+}
+
+void bbgpu_set_timing(int enabled)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    g_ctx.timing = enabled != 0;
+}
+int bbgpu_last_timing(float* ms_out, int max_entries)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int k = g_ctx.last.count < max_entries ? g_ctx.last.count : max_entries;
+    for (int i = 0; i < k; i++) ms_out[i] = g_ctx.last.ms[i];
+    return k;
+}
+
+/* ---- NTT ---- */
+int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* constant, void* hip_stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    const int lg = log2_exact(n);
+    if (lg < 1) {
+        set_error("NTT size %zu is not a power of two >= 2", n);
+        return BBGPU_ERR_SIZE;
+    }
+    if (kind < 0 || kind > BBGPU_COSET_FFT_WITH_CONSTANT || !d_coeffs) {
+        set_error("bad NTT kind / null buffer");
+        return BBGPU_ERR_ARG;
+    }
+    rc = grow(&g_ctx.d_scratch, &g_ctx.scratch_cap, n * 32);
+    if (rc) return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    rc = ntt_device(d_coeffs, g_ctx.d_scratch, lg, kind, constant, st);
+    if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^22)", lg);
+    if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!coeffs) return BBGPU_ERR_ARG;
+    rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
+    if (rc) return rc;
+    CHK(hipMemcpyAsync(g_ctx.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+    rc = bbgpu_ntt_device(g_ctx.d_stage, n, kind, constant, g_ctx.stream);
+    if (rc) return rc;
+    CHK(hipMemcpyAsync(coeffs, g_ctx.d_stage, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
+    CHK(hipStreamSynchronize(g_ctx.stream));
+    return BBGPU_OK;
+}
+
+/* ---- SRS ---- */
+int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!points_endo_table || n == 0) return BBGPU_ERR_ARG;
+    size_t off;
+    int idx = find_srs(points_endo_table, n, &off);
+    if (idx >= 0 && off == 0) return idx;
+    uint32_t* d = nullptr;
+    rc = srs_upload(points_endo_table, n, &d, g_ctx.stream);
+    if (rc) return rc;
+    g_ctx.srs.push_back({ points_endo_table, n, d, true });
+    return (int)g_ctx.srs.size() - 1;
+}
+
+int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!x_mont || n == 0) return BBGPU_ERR_ARG;
+    uint32_t* d = nullptr;
+    rc = srs_generate(x_mont, n, &d, host_endo_table_out, g_ctx.stream);
+    if (rc) return rc;
+    g_ctx.srs.push_back({ host_endo_table_out, n, d, true });
+    return (int)g_ctx.srs.size() - 1;
+}
+
+int bbgpu_srs_release(int handle)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (handle < 0 || handle >= (int)g_ctx.srs.size() || !g_ctx.srs[handle].live) return BBGPU_ERR_ARG;
+    (void)hipStreamSynchronize(g_ctx.stream);
+    (void)hipFree(g_ctx.srs[handle].d_srs);
+    g_ctx.srs[handle].live = false;
+    g_ctx.srs[handle].d_srs = nullptr;
+    return BBGPU_OK;
+}
+
+/* ---- MSM ---- */
+int bbgpu_msm_num_windows(size_t n)
+{
+    return msm_num_windows(msm_choose_c(n ? n : 1));
+}
+
+int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    return msm_host_ptrs(scalars, points_endo_table, n, out);
+}
+
+int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (num_jobs == 0) return BBGPU_OK;
+    if (!jobs) return BBGPU_ERR_ARG;
+    for (size_t i = 1; i < num_jobs; i++) {
+        if (jobs[i].num_elements != jobs[0].num_elements) {
+            // scalar_multiplication.cpp:678-685: report and leave the outputs untouched
+            set_error("batched_scalar_multiplications err: each scalar mul must be same size.");
+            return BBGPU_ERR_ARG;
+        }
+    }
+    for (size_t i = 0; i < num_jobs; i++) {
+        rc = msm_host_ptrs(jobs[i].scalars, jobs[i].points, jobs[i].num_elements, jobs[i].output);
+        if (rc) return rc;
+    }
+    return BBGPU_OK;
+}
+
+int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin, int window_end,
+                        uint64_t out[12], void* hip_stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (srs_handle < 0 || srs_handle >= (int)g_ctx.srs.size() || !g_ctx.srs[srs_handle].live) {
+        set_error("unknown SRS handle %d", srs_handle);
+        return BBGPU_ERR_ARG;
+    }
+    const SrsEntry& e = g_ctx.srs[srs_handle];
+    if (offset + n > e.n || (!d_scalars && n)) {
+        set_error("MSM range [%zu, %zu) outside the registered table of %zu points", offset, offset + n, e.n);
+        return BBGPU_ERR_ARG;
+    }
+    host::Xyzz res;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    rc = msm_run(g_ctx.ws, e.d_srs + offset * 16, d_scalars, n, window_begin, window_end, &res, st, g_ctx.timing ? &g_ctx.last : nullptr);
+    if (rc == BBGPU_ERR_ARG) set_error("bad window range [%d, %d)", window_begin, window_end);
+    if (rc) return rc;
+    host::g1_to_normalised(res, out);
+    return BBGPU_OK;
+}
+
+int bbgpu_g1_sum(const uint64_t* points12, size_t count, uint64_t out[12])
+{
+    if (!out || (count && !points12)) return BBGPU_ERR_ARG;
+    host::Xyzz acc = host::g1_infinity();
+    for (size_t i = 0; i < count; i++) acc = host::g1_add(acc, host::g1_from_jacobian(points12 + 12 * i));
+    host::g1_to_normalised(acc, out);
+    return BBGPU_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,678 @@
+// msm.hip -- Pippenger multi-scalar multiplication over BN254 G1 for gfx950.
+//
+// Replaces scalar_multiplication::pippenger / pippenger_internal / compute_wnaf_state
+// (reference src/barretenberg/curves/bn254/scalar_multiplication.cpp:265-308,457-476,576-648).
+// The reference is a serial bucket method: per scalar an endomorphism split + wNAF (a6,a7), then for each of 8 rounds
+// 2n dependent mixed-adds into 2^15 Jacobian buckets with software prefetch, then a serial running sum.  None of
+// that shape survives here; what survives is the mathematics (sum_i k_i P_i) and the output contract.
+//
+// MI355X design (DESIGN.md has the measurements behind each choice):
+//   * scalars: from-Montgomery and signed base-2^c digits in one pass (K0).  No GLV split: with the bucket work
+//     spread over W * 2^(c-1) independent accumulators the endomorphism buys nothing on a GPU, and reading only the
+//     even (base) entries of the caller's endo table halves point traffic.
+//   * binning instead of scatter-add: per window a counting sort of point indices by bucket, histograms and cursors
+//     private to a workgroup in LDS (128 KiB of the CU's 160 KiB at c = 16), no global atomics (K1-K3).
+//   * accumulation (K4, ~90% of the time): one lane per (window, bucket), XYZZ accumulator in VGPRs, points gathered
+//     from the resident SRS in the kernels' Montgomery-261 form; 524,288 independent chains at n = 2^20 keep every
+//     SIMD issuing v_mad_u64_u32.  Integer-VALU bound: 2^20 * 16 madds * 10 field multiplies.
+//   * bucket reduction (K5): sum_b (b+1) B_b per window without a serial running sum: row sums and column sums of the
+//     bucket matrix by log-depth folds, then bit-sliced sums; the O(c) leftover points per window are combined by the
+//     host with ~256 doublings (host_g1.hpp) and normalised once.
+//   * multi-GPU: windows are independent, so rank g takes a window range and returns a normalised partial sum.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "bbgpu_internal.h"
+#include "g1.cuh"
+#include "host_g1.hpp"
+
+namespace bbgpu {
+
+using Fr = FrP;
+constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
+constexpr int MSM_MAX_C = 16;    // digits stored as int16, LDS histogram of 2^15 counters
+constexpr int MSM_THREADS = 256;
+
+__device__ __forceinline__ void ld8(const uint32_t* p, uint32_t (&w)[8])
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void ld16(const uint32_t* p, uint32_t (&w)[16])
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint4 a = q[i];
+        w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w;
+    }
+}
+__device__ __forceinline__ void st32(uint32_t* p, const uint32_t (&w)[32])
+{
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void ld32(const uint32_t* p, uint32_t (&w)[32])
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint4 a = q[i];
+        w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SRS: reference endo table (2n x 64 B, Montgomery 2^256) -> resident base points (n x 64 B, Montgomery 2^261, canonical)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void srs_convert_kernel(const uint32_t* __restrict__ table, uint32_t* __restrict__ srs, uint32_t n, uint32_t stride_words)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[16];
+    ld16(table + (size_t)i * stride_words, w);
+    AffineV<2> a;
+    load_affine_m256(a, w);
+    uint32_t o[16];
+    store_affine_m261(o, a.x, a.y);
+    uint4* q = reinterpret_cast<uint4*>(srs + (size_t)i * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// resident points -> reference endo table entries 2i (P) and 2i+1 (beta*x, -y), Montgomery 2^256  (a9)
+__global__ void srs_export_kernel(const uint32_t* __restrict__ srs, uint32_t* __restrict__ table, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[16];
+    ld16(srs + (size_t)i * 16, w);
+    AffineV<1> a;
+    load_affine_m261(a, w);
+    uint32_t o[8];
+    uint32_t* dst = table + (size_t)i * 32;
+    to_canonical(m261_to_m256<Fq>(a.x), o);
+    for (int k = 0; k < 8; k++) dst[k] = o[k];
+    to_canonical(m261_to_m256<Fq>(a.y), o);
+    for (int k = 0; k < 8; k++) dst[8 + k] = o[k];
+    auto bx = mul(a.x, fe_from<Fq>(Fq::BETA));
+    to_canonical(m261_to_m256<Fq>(bx), o);
+    for (int k = 0; k < 8; k++) dst[16 + k] = o[k];
+    to_canonical(m261_to_m256<Fq>(weak(neg(a.y))), o);
+    for (int k = 0; k < 8; k++) dst[24 + k] = o[k];
+}
+
+// ---- synthetic SRS x^i G (fixed-base, 8-bit windows) ----------------------------------------------------------------
+// tab[w][d] = d * 2^(8w) * G as XYZZ words, d in [0,256) (d = 0: infinity)
+__global__ void srs_gen_table_kernel(uint32_t* __restrict__ tab)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= 32) return;
+    Xyzz base;
+    AffineV<1> g;
+    g.x = fe_from<Fq>(Fq::GEN_X);
+    g.y = fe_from<Fq>(Fq::GEN_Y);
+    from_affine(base, g);
+    for (uint32_t k = 0; k < 8 * w; k++) {
+        Xyzz t;
+        dbl(t, base);
+        base = t;
+    }
+    Xyzz acc;
+    set_infinity(acc);
+    for (uint32_t d = 0; d < 256; d++) {
+        uint32_t o[32];
+        store_xyzz(o, acc);
+        st32(tab + ((size_t)w * 256 + d) * 32, o);
+        Xyzz t;
+        add(t, acc, base);
+        acc = t;
+    }
+}
+__device__ __forceinline__ Fe<Fq, 1, 2> fq_inverse(const Fe<Fq, 1, 2>& a)
+{
+    const uint64_t e[4] = { Fq::P64[0] - 2, Fq::P64[1], Fq::P64[2], Fq::P64[3] };
+    return pow_u256<Fq>(a, e);
+}
+// srs[i] = x^i * G, affine canonical Montgomery-261
+__global__ void srs_gen_points_kernel(const uint32_t* __restrict__ tab, Limbs9 x261, uint32_t* __restrict__ srs, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // s = x^i in Fr (Montgomery-261), then plain canonical
+    Fe<Fr, 1, 2> s = fe_one<Fr>(), b = fe_from<Fr>(x261.d);
+    for (uint32_t e = i; e; e >>= 1) {
+        if (e & 1) s = mul(s, b);
+        b = sqr(b);
+    }
+    uint32_t k[8];
+    {
+        FeT<Fr> one_raw = fe_zero<Fr>();
+        one_raw.d[0] = 1;
+        to_canonical(mul(s, one_raw), k); // s * R^-1 = plain value
+    }
+    Xyzz acc;
+    set_infinity(acc);
+    for (uint32_t w = 0; w < 32; w++) {
+        const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xff;
+        if (d) {
+            uint32_t pw[32];
+            ld32(tab + ((size_t)w * 256 + d) * 32, pw);
+            Xyzz q;
+            load_xyzz(q, pw);
+            Xyzz t;
+            add(t, acc, q);
+            acc = t;
+        }
+    }
+    // affine: x = X / ZZ, y = Y / ZZZ (x^i != 0 mod r so the point is finite)
+    auto inv = fq_inverse(mul(acc.zz, acc.zzz));
+    auto izz = mul(inv, acc.zzz), izzz = mul(inv, acc.zz);
+    uint32_t o[16];
+    store_affine_m261(o, mul(acc.x, izz), mul(acc.y, izzz));
+    uint4* q = reinterpret_cast<uint4*>(srs + (size_t)i * 16);
+#pragma unroll
+    for (int t = 0; t < 4; t++) q[t] = make_uint4(o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K0: scalars (Montgomery 2^256, any representative) -> signed digits, window-major int16
+//     d in [-2^(c-1), 2^(c-1)),  k = sum_w d_w 2^(c w);  replaces a5 + a6 + a7 (from_montgomery, endo split, wNAF)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
+                                                               uint32_t n, uint32_t c, uint32_t num_windows)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[8], k[9];
+    ld8(scalars + (size_t)i * 8, w);
+    to_canonical(mul(unpack<Fr>(w), fe_from<Fr>(Fr::M256_TO_PLAIN)), w); // x*2^256 * 2^5 / 2^261 = x, canonical
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = w[j];
+    k[8] = 0;
+    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+    uint32_t carry = 0;
+    for (uint32_t win = 0; win < num_windows; win++) {
+        const uint32_t bit = win * c, j = bit >> 5, s = bit & 31;
+        uint32_t v = 0;
+        if (j < 8) {
+            v = k[j] >> s;
+            if (s + c > 32) v |= k[j + 1] << (32 - s);
+        }
+        v = (v & mask) + carry;
+        carry = v >= half ? 1u : 0u;
+        const int32_t d = (int32_t)v - (int32_t)(carry << c);
+        digits[(size_t)win * n + i] = (int16_t)d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K1/K3: per (slice, window) counting sort, histogram / cursors in LDS
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 1024;
+__global__ void __launch_bounds__(SORT_THREADS) msm_hist_kernel(const int16_t* __restrict__ digits, uint32_t* __restrict__ hist, uint32_t n,
+                                                              uint32_t nb, uint32_t slices, uint32_t slice_len, uint32_t win0)
+{
+    extern __shared__ uint32_t lh[];
+    const uint32_t s = blockIdx.x, wl = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) lh[b] = 0;
+    __syncthreads();
+    const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
+    const int16_t* dg = digits + (size_t)(win0 + wl) * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        const int d = dg[i];
+        if (d) atomicAdd(&lh[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = hist + ((size_t)wl * slices + s) * nb;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) out[b] = lh[b];
+}
+
+// K2: per window: bucket starts (exclusive scan over buckets of the per-bucket totals) and per-slice cursors (in place)
+__global__ void __launch_bounds__(SORT_THREADS) msm_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bstart, uint32_t nb, uint32_t slices)
+{
+    __shared__ uint32_t part[SORT_THREADS];
+    const uint32_t wl = blockIdx.x, t = threadIdx.x;
+    uint32_t* H = hist + (size_t)wl * slices * nb;
+    const uint32_t per = (nb + SORT_THREADS - 1) / SORT_THREADS;
+    const uint32_t b0 = t * per, b1 = min(nb, b0 + per);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++)
+        for (uint32_t s = 0; s < slices; s++) sum += H[(size_t)s * nb + b];
+    part[t] = sum;
+    __syncthreads();
+    // exclusive scan of part[] (Hillis-Steele, 1024 entries)
+    for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t b = b0; b < b1; b++) {
+        bstart[(size_t)wl * (nb + 1) + b] = run;
+        for (uint32_t s = 0; s < slices; s++) {
+            const uint32_t cnt = H[(size_t)s * nb + b];
+            H[(size_t)s * nb + b] = run;
+            run += cnt;
+        }
+    }
+    if (t == SORT_THREADS - 1) bstart[(size_t)wl * (nb + 1) + nb] = part[SORT_THREADS - 1];
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) msm_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursors,
+                                                                 uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb, uint32_t slices,
+                                                                 uint32_t slice_len, uint32_t win0)
+{
+    extern __shared__ uint32_t lc[];
+    const uint32_t s = blockIdx.x, wl = blockIdx.y;
+    const uint32_t* cur = cursors + ((size_t)wl * slices + s) * nb;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) lc[b] = cur[b];
+    __syncthreads();
+    const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
+    const int16_t* dg = digits + (size_t)(win0 + wl) * n;
+    uint32_t* out = sorted + (size_t)wl * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        const int d = dg[i];
+        if (d) {
+            const uint32_t pos = atomicAdd(&lc[(d < 0 ? -d : d) - 1], 1u);
+            out[pos] = i | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K4: bucket accumulation -- the hot loop (replaces scalar_multiplication.cpp:604-617)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
+                                                                   const uint32_t* __restrict__ bstart, uint32_t* __restrict__ buckets,
+                                                                   uint32_t n, uint32_t nb, uint32_t total_buckets)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_buckets) return;
+    const uint32_t wl = t / nb, b = t - wl * nb;
+    const uint32_t* bs = bstart + (size_t)wl * (nb + 1);
+    uint32_t e = bs[b];
+    const uint32_t end = bs[b + 1];
+    const uint32_t* ent = sorted + (size_t)wl * n;
+    Xyzz acc;
+    set_infinity(acc);
+    for (; e < end; e++) {
+        const uint32_t v = ent[e];
+        uint32_t w[16];
+        ld16(srs + (size_t)(v & 0x7fffffffu) * 16, w);
+        AffineV<1> p;
+        load_affine_m261(p, w);
+        madd(acc, cond_neg_affine(p, (v >> 31) != 0));
+    }
+    uint32_t o[32];
+    store_xyzz(o, acc);
+    st32(buckets + (size_t)t * 32, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K5: log-depth folds over arrays of XYZZ points (32 words each)
+// ---------------------------------------------------------------------------------------------------------------------
+struct FoldJob {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t groups;      // independent segments
+    uint32_t half;        // out[g][j] = in[g][j] + in[g][j + half], j < half
+    uint32_t in_gstride;  // in points
+    uint32_t out_gstride;
+};
+struct FoldArgs {
+    FoldJob job[3];
+    uint32_t njobs;
+};
+__global__ void __launch_bounds__(MSM_THREADS) msm_fold_kernel(FoldArgs A)
+{
+    const FoldJob& J = A.job[blockIdx.y];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= J.groups * J.half) return;
+    const uint32_t g = t / J.half, j = t - g * J.half;
+    uint32_t w[32];
+    Xyzz p, q, r;
+    ld32(J.in + ((size_t)g * J.in_gstride + j) * 32, w);
+    load_xyzz(p, w);
+    ld32(J.in + ((size_t)g * J.in_gstride + j + J.half) * 32, w);
+    load_xyzz(q, w);
+    add(r, p, q);
+    store_xyzz(w, r);
+    st32(J.out + ((size_t)g * J.out_gstride + j) * 32, w);
+}
+
+// bit-sliced gather + first fold.  For every group g, bit k < bits (len = 2^bits), pair j < len/4:
+//   out[(g*bits + k)*(len/4) + j] = in[g*len + sel_k(2j)] + in[g*len + sel_k(2j+1)],  sel_k(m) = m-th index with bit k set.
+// len == 2 degenerates to a copy of in[g*2 + 1].
+struct SliceJob {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t groups, bits, len;
+};
+struct SliceArgs {
+    SliceJob job[2];
+};
+__device__ __forceinline__ uint32_t insert_one_bit(uint32_t m, uint32_t k)
+{
+    return ((m >> k) << (k + 1)) | (1u << k) | (m & ((1u << k) - 1));
+}
+__global__ void __launch_bounds__(MSM_THREADS) msm_slice_kernel(SliceArgs A)
+{
+    const SliceJob& J = A.job[blockIdx.y];
+    const uint32_t quarter = J.len >= 4 ? (J.len >> 2) : 1;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= J.groups * J.bits * quarter) return;
+    const uint32_t j = t % quarter, gk = t / quarter, k = gk % J.bits, g = gk / J.bits;
+    uint32_t w[32];
+    if (J.len == 2) {
+        ld32(J.in + ((size_t)g * 2 + 1) * 32, w);
+        st32(J.out + (size_t)t * 32, w);
+        return;
+    }
+    Xyzz p, q, r;
+    ld32(J.in + ((size_t)g * J.len + insert_one_bit(2 * j, k)) * 32, w);
+    load_xyzz(p, w);
+    ld32(J.in + ((size_t)g * J.len + insert_one_bit(2 * j + 1, k)) * 32, w);
+    load_xyzz(q, w);
+    add(r, p, q);
+    store_xyzz(w, r);
+    st32(J.out + (size_t)t * 32, w);
+}
+
+// final: per window gather Z, TR_k, TC_k into 64 slots and convert to the reference's Montgomery(2^256) words
+//   slot 0 = Z, 1 + k = TR_k (k < hbits), 32 + k = TC_k (k < lbits); unused slots are infinity
+__global__ void msm_collect_kernel(const uint32_t* __restrict__ z, const uint32_t* __restrict__ tr, const uint32_t* __restrict__ tc,
+                                   uint32_t* __restrict__ out, uint32_t nw, uint32_t hbits, uint32_t lbits)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nw * 64) return;
+    const uint32_t w = t >> 6, slot = t & 63;
+    const uint32_t* src = nullptr;
+    if (slot == 0) src = z + (size_t)w * 32;
+    else if (slot >= 1 && slot < 1 + hbits) src = tr + ((size_t)w * hbits + (slot - 1)) * 32;
+    else if (slot >= 32 && slot < 32 + lbits) src = tc + ((size_t)w * lbits + (slot - 32)) * 32;
+    uint32_t o[32];
+    Xyzz p;
+    if (src) {
+        ld32(src, o);
+        load_xyzz(p, o);
+    } else {
+        set_infinity(p);
+    }
+    store_xyzz_m256(o, p);
+    st32(out + (size_t)t * 32, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------------------------
+#define HIPCHK(x)                                                                                                      \
+    do {                                                                                                               \
+        hipError_t e_ = (x);                                                                                           \
+        if (e_ != hipSuccess) {                                                                                        \
+            set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));                                \
+            return BBGPU_ERR_HIP;                                                                                      \
+        }                                                                                                              \
+    } while (0)
+
+int msm_choose_c(size_t n)
+{
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    int c = lg - 4;
+    if (c < 4) c = 4;
+    if (c > MSM_MAX_C) c = MSM_MAX_C;
+    return c;
+}
+int msm_num_windows(int c)
+{
+    return SCALAR_BITS / c + 1;
+}
+
+struct MsmPlan {
+    uint32_t n, c, W, nb, hbits, lbits, slices, slice_len;
+};
+static MsmPlan make_plan(size_t n, int c)
+{
+    MsmPlan P;
+    P.n = (uint32_t)n;
+    P.c = (uint32_t)c;
+    P.W = (uint32_t)msm_num_windows(c);
+    P.nb = 1u << (c - 1);
+    P.lbits = (c - 1) / 2;
+    P.hbits = (c - 1) - P.lbits;
+    P.slices = std::max<uint32_t>(1, 256 / P.W);
+    if ((uint64_t)P.slices * 4096 > n) P.slices = std::max<uint32_t>(1, (uint32_t)(n / 4096));
+    P.slice_len = (uint32_t)((n + P.slices - 1) / P.slices);
+    return P;
+}
+
+// workspace sizes in bytes for a window range of `nw` windows
+size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
+{
+    MsmPlan P = make_plan(n, c);
+    size_t tot = 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    tot += al((size_t)P.W * n * 2);                          // digits
+    tot += al((size_t)nw * P.slices * P.nb * 4);             // hist / cursors
+    tot += al((size_t)nw * (P.nb + 1) * 4);                  // bstart
+    tot += al((size_t)nw * n * 4);                           // sorted
+    tot += al((size_t)nw * P.nb * 128);                      // buckets
+    tot += al(((size_t)nw * P.nb * 2 + 4096) * 128);         // fold arena: rows < nb, cols < nb, slices/Z small
+    tot += al((size_t)nw * 64 * 128);                        // exported T points
+    return tot;
+}
+
+int MsmWorkspace::ensure(size_t bytes)
+{
+    if (bytes <= cap) return BBGPU_OK;
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = 0;
+    HIPCHK(hipMalloc((void**)&base, bytes));
+    cap = bytes;
+    return BBGPU_OK;
+}
+void MsmWorkspace::release()
+{
+    if (base) (void)hipFree(base);
+    if (h_out) (void)hipHostFree(h_out);
+    base = nullptr;
+    h_out = nullptr;
+    cap = 0;
+}
+
+// Runs windows [wb, we) of the MSM of d_scalars[0..n) against resident points srs[0..n); returns the partial sum
+// sum_{w in [wb,we)} 2^(c w) S_w as host XYZZ (Montgomery 2^256).
+int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, host::Xyzz* result,
+            hipStream_t st, MsmTiming* timing)
+{
+    *result = host::g1_infinity();
+    if (n == 0) return BBGPU_OK;
+    const int c = msm_choose_c(n);
+    const MsmPlan P = make_plan(n, c);
+    if (wb < 0 || we > (int)P.W || wb >= we) return BBGPU_ERR_ARG;
+    const uint32_t nw = (uint32_t)(we - wb);
+    int rc = ws.ensure(MsmWorkspace::bytes_needed(n, c, (int)nw));
+    if (rc) return rc;
+    if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, 64 * 64 * 128));
+
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    uint8_t* p = ws.base;
+    int16_t* digits = (int16_t*)p; p += al((size_t)P.W * n * 2);
+    uint32_t* hist = (uint32_t*)p; p += al((size_t)nw * P.slices * P.nb * 4);
+    uint32_t* bstart = (uint32_t*)p; p += al((size_t)nw * (P.nb + 1) * 4);
+    uint32_t* sorted = (uint32_t*)p; p += al((size_t)nw * n * 4);
+    uint32_t* buckets = (uint32_t*)p; p += al((size_t)nw * P.nb * 128);
+    uint32_t* scratch = (uint32_t*)p; p += al(((size_t)nw * P.nb * 2 + 4096) * 128);
+    uint32_t* texp = (uint32_t*)p;
+
+    hipEvent_t ev[8];
+    const bool tm = timing != nullptr;
+    if (tm) {
+        for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventRecord(ev[0], st));
+    }
+
+    // K0
+    msm_digits_kernel<<<(P.n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>((const uint32_t*)d_scalars, digits, P.n, P.c, P.W);
+    if (tm) HIPCHK(hipEventRecord(ev[1], st));
+    // K1-K3
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MSM_MAX_C - 1)) * 4));
+        HIPCHK(hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MSM_MAX_C - 1)) * 4));
+        attr = true;
+    }
+    msm_hist_kernel<<<dim3(P.slices, nw), SORT_THREADS, P.nb * 4, st>>>(digits, hist, P.n, P.nb, P.slices, P.slice_len, (uint32_t)wb);
+    msm_scan_kernel<<<nw, SORT_THREADS, 0, st>>>(hist, bstart, P.nb, P.slices);
+    msm_scatter_kernel<<<dim3(P.slices, nw), SORT_THREADS, P.nb * 4, st>>>(digits, hist, sorted, P.n, P.nb, P.slices, P.slice_len, (uint32_t)wb);
+    if (tm) HIPCHK(hipEventRecord(ev[2], st));
+    // K4
+    const uint32_t total_buckets = nw * P.nb;
+    msm_accumulate_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(d_srs, sorted, bstart, buckets, P.n, P.nb, total_buckets);
+    if (tm) HIPCHK(hipEventRecord(ev[3], st));
+
+    // K5: bucket b = hi * 2^l + lo carries weight b + 1:
+    //   S_w = Z + sum_lo lo * C_lo + 2^l * sum_hi hi * R_hi,   R = row sums (over lo), C = column sums (over hi), Z = sum R
+    //   sum_hi hi * R_hi = sum_k 2^k TR_k, TR_k = sum of the R_hi whose bit k is set (same for C).
+    const uint32_t H = 1u << P.hbits, L = 1u << P.lbits;
+    uint32_t* bump = scratch;
+    auto alloc_pts = [&](size_t count) { uint32_t* r = bump; bump += count * 32; return r; };
+    struct Chain { const uint32_t* in; uint32_t groups, len, stop, gstride; };
+    auto run_chains = [&](Chain* ch, int nch) -> int {
+        for (;;) {
+            FoldArgs FA{};
+            uint32_t mt = 0;
+            for (int q = 0; q < nch; q++) {
+                Chain& C = ch[q];
+                if (C.len <= C.stop) continue;
+                FoldJob& J = FA.job[FA.njobs++];
+                J.in = C.in; J.groups = C.groups; J.half = C.len / 2; J.in_gstride = C.gstride; J.out_gstride = C.len / 2;
+                J.out = alloc_pts((size_t)C.groups * J.half);
+                mt = std::max(mt, J.groups * J.half);
+                C.in = J.out; C.len /= 2; C.gstride = C.len;
+            }
+            if (FA.njobs == 0) return BBGPU_OK;
+            msm_fold_kernel<<<dim3((mt + MSM_THREADS - 1) / MSM_THREADS, FA.njobs), MSM_THREADS, 0, st>>>(FA);
+        }
+    };
+    // rows: groups = (window, hi), contiguous length L -> 1.  cols: groups = window, length nb folded by halves of the hi
+    // range until L entries (the column sums) remain.
+    Chain rowcol[2] = { { buckets, nw * H, L, 1, L }, { buckets, nw, P.nb, L, P.nb } };
+    run_chains(rowcol, 2);
+    const uint32_t* R = rowcol[0].in;  // [nw][H]
+    const uint32_t* Cc = rowcol[1].in; // [nw][L]
+    if (tm) HIPCHK(hipEventRecord(ev[4], st));
+    uint32_t* trbuf = alloc_pts((size_t)nw * P.hbits * std::max(1u, H / 4));
+    uint32_t* tcbuf = alloc_pts((size_t)nw * std::max(1u, P.lbits) * std::max(1u, L / 4));
+    {
+        SliceArgs SA{};
+        uint32_t nj = 0, mt = 0;
+        if (P.hbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = R; J.out = trbuf; J.groups = nw; J.bits = P.hbits; J.len = H; mt = std::max(mt, nw * P.hbits * std::max(1u, H / 4)); }
+        if (P.lbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = Cc; J.out = tcbuf; J.groups = nw; J.bits = P.lbits; J.len = L; mt = std::max(mt, nw * P.lbits * std::max(1u, L / 4)); }
+        if (nj) msm_slice_kernel<<<dim3((mt + MSM_THREADS - 1) / MSM_THREADS, nj), MSM_THREADS, 0, st>>>(SA);
+    }
+    Chain zt[3] = { { R, nw, H, 1, H },
+                    { trbuf, nw * P.hbits, std::max(1u, H / 4), 1, std::max(1u, H / 4) },
+                    { tcbuf, nw * std::max(1u, P.lbits), std::max(1u, L / 4), 1, std::max(1u, L / 4) } };
+    run_chains(zt, 3);
+    msm_collect_kernel<<<(nw * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, nw, P.hbits, P.lbits);
+    if (tm) HIPCHK(hipEventRecord(ev[5], st));
+    HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)nw * 64 * 128, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+
+    // ---- host tail: S_w = Z + sum_k 2^k TC_k + 2^l sum_k 2^k TR_k ; result = sum_w 2^(c w) S_w (Horner from the top) --
+    auto pt = [&](uint32_t w, uint32_t slot) {
+        host::Xyzz q;
+        memcpy(&q, (const uint8_t*)ws.h_out + ((size_t)w * 64 + slot) * 128, 128);
+        return q;
+    };
+    host::Xyzz acc = host::g1_infinity();
+    for (int w = (int)nw - 1; w >= 0; --w) {
+        host::Xyzz rs = host::g1_infinity();
+        for (int k = (int)P.hbits - 1; k >= 0; --k) rs = host::g1_add(host::g1_dbl(rs), pt(w, 1 + k));
+        for (uint32_t k = 0; k < P.lbits; k++) rs = host::g1_dbl(rs);
+        host::Xyzz cs = host::g1_infinity();
+        for (int k = (int)P.lbits - 1; k >= 0; --k) cs = host::g1_add(host::g1_dbl(cs), pt(w, 32 + k));
+        host::Xyzz sw = host::g1_add(host::g1_add(rs, cs), pt(w, 0));
+        for (uint32_t k = 0; k < P.c; k++) acc = host::g1_dbl(acc);
+        acc = host::g1_add(acc, sw);
+    }
+    for (uint32_t k = 0; k < P.c * (uint32_t)wb; k++) acc = host::g1_dbl(acc);
+    *result = acc;
+
+    if (tm) {
+        float ms;
+        timing->count = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
+        timing->ms[timing->count++] = ms;
+        for (int i = 0; i < 5; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            timing->ms[timing->count++] = ms;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return BBGPU_OK;
+}
+
+// ---- SRS management --------------------------------------------------------------------------------------------------
+int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st)
+{
+    uint32_t* d_tab = nullptr;
+    uint32_t* d_srs = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tab, n * 128));
+    HIPCHK(hipMalloc((void**)&d_srs, n * 64));
+    HIPCHK(hipMemcpyAsync(d_tab, host_endo_table, n * 128, hipMemcpyHostToDevice, st));
+    srs_convert_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_tab, d_srs, (uint32_t)n, 32);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(d_tab));
+    *d_srs_out = d_srs;
+    return BBGPU_OK;
+}
+
+int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st)
+{
+    uint32_t* d_tab = nullptr;
+    uint32_t* d_srs = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tab, 32 * 256 * 128));
+    HIPCHK(hipMalloc((void**)&d_srs, n * 64));
+    srs_gen_table_kernel<<<1, 32, 0, st>>>(d_tab);
+    // x: Montgomery 2^256 -> 2^261
+    uint32_t w[8];
+    for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)x_mont256[i]; w[2 * i + 1] = (uint32_t)(x_mont256[i] >> 32); }
+    Fe<Fr, 1, 2> x261 = m256_to_m261<Fr>(unpack<Fr>(w));
+    uint32_t cw[8];
+    to_canonical(x261, cw);
+    Fe<Fr, 1, 6> xc = unpack<Fr>(cw);
+    Limbs9 xl;
+    for (int i = 0; i < NL; i++) xl.d[i] = xc.d[i];
+    srs_gen_points_kernel<<<(uint32_t)((n + 63) / 64), 64, 0, st>>>(d_tab, xl, d_srs, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    if (host_table_out) {
+        uint32_t* d_exp = nullptr;
+        HIPCHK(hipMalloc((void**)&d_exp, n * 128));
+        srs_export_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_srs, d_exp, (uint32_t)n);
+        HIPCHK(hipMemcpyAsync(host_table_out, d_exp, n * 128, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(d_exp));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(d_tab));
+    *d_srs_out = d_srs;
+    return BBGPU_OK;
+}
+
+} // namespace bbgpu

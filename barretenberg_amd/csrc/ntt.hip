@@ -1,0 +1,432 @@
+// ntt.hip -- radix-2 NTT / coset-FFT over BN254 Fr for gfx950.
+//
+// Replaces polynomial_arithmetic::fft / ifft / coset_fft / coset_ifft / *_with_constant
+// (reference src/barretenberg/polynomials/polynomial_arithmetic.cpp:129-315, scale_by_generator :81-102).
+// Contract kept: natural order in, natural order out, in place on n x 32-byte Montgomery(2^256) elements,
+// inputs anywhere in [0, 2^256) (the prover hands [0,2p)), outputs canonical [0,p).
+//
+// Structure (MI355X-first, not the reference's log2(n) streaming rounds over a 2n-entry twiddle table):
+//   n = n1 * n2, two HBM passes ("four-step"), each pass runs complete n1- / n2-point sub-transforms inside LDS:
+//     pass 1: for every column j2: A[k1][j2] = sum_j1 x[j1*n2 + j2] w_n1^(j1 k1); then twist by w_n^(j2 k1)
+//     pass 2: for every row k1:    X[k1 + n1 k2] = sum_j2 A[k1][j2] w_n2^(j2 k2)
+//   so the vector crosses HBM twice (read+write) instead of ~log2(n) times, and twiddles are tiny tables
+//   (n1/2 + n2/2 + 2*sqrt(n) entries) generated on the device -- the reference's 64 MiB table never exists.
+//   Coset / inverse / constant scalings are fused into the first load and the last store.
+//   Data stays in the reference's Montgomery(2^256) form end to end: only twiddles live in our 2^261 form, since
+//   mont261(x * 2^256, w * 2^261) = x w 2^256.
+// Field arithmetic: fe.cuh (9 x 29-bit limbs, lazy; ~163 v_mad_u64_u32 per multiply).  The kernels are bound by
+// the integer VALU rate, not HBM: (n/2) log2 n + ~2n multiplies at ~1.4e11 mul/s.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <stdint.h>
+#include <stdio.h>
+#include <unordered_map>
+
+#include "bbgpu_internal.h"
+#include "fe.cuh"
+
+namespace bbgpu {
+
+using Fr = FrP;
+constexpr int NTT_VMAX = 48;                 // lazy value bound inside one pass: 6 + 3 * 12 stages + slack
+using FrL = Fe<Fr, 1, NTT_VMAX>;             // LDS-resident element
+constexpr int NTT_MAX_LOG_SUB = 11;          // sub-transform up to 2048 points (72 KiB of LDS)
+constexpr int NTT_LDS_ELEMS = 2048;          // elements of LDS per workgroup (9 words each = 72 KiB) -> 2 WG / CU
+constexpr int NTT_THREADS = 512;
+
+// proof obligation is the caller's: the true bounds are <= (L, V)
+template <int L, int V, class F, int L2, int V2> BB_HD Fe<F, L, V> assume_bound(const Fe<F, L2, V2>& a)
+{
+    Fe<F, L, V> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.d[i] = a.d[i];
+    return r;
+}
+
+__device__ __forceinline__ void load8(const uint32_t* p, uint32_t (&w)[8])
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store8(uint32_t* p, const uint32_t (&w)[8])
+{
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// table entries are canonical Montgomery-261 values packed as 8 words
+__device__ __forceinline__ FeT<Fr> load_tw(const uint32_t* table, uint32_t idx)
+{
+    uint32_t w[8];
+    load8(table + 8 * (size_t)idx, w);
+    return assume_bound<1, 1>(unpack<Fr>(w));
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits)
+{
+    return __brev(x) >> (32 - bits);
+}
+
+struct NttPassArgs {
+    const uint32_t* in;       // n x 8 words
+    uint32_t* out;            // n x 8 words
+    const uint32_t* tw_sub;   // w_S^k, k < S/2
+    const uint32_t* twist_lo; // w_n^l, l < 2^lo_bits          (pass 1 only)
+    const uint32_t* twist_hi; // w_n^(h << lo_bits)
+    const uint32_t* scale_lo; // g^l (pre) or g^-l (post) two-level tables, lo part
+    const uint32_t* scale_hi;
+    uint32_t post_const[NL];  // Montgomery-261 constant applied to every output of the last pass
+    uint32_t log_s;           // sub-transform size S = 2^log_s
+    uint32_t log_b;           // number of sub-transforms B = 2^log_b   (n = S * B)
+    uint32_t cols, log_cols;  // sub-transforms per workgroup (power of two, cols * S <= NTT_LDS_ELEMS)
+    uint32_t in_sa, in_sb;    // element (a, b) is read from in[a * in_sa + b * in_sb]
+    uint32_t out_sa, out_sb;  // result (k, b) is written to out[k * out_sa + b * out_sb]
+    uint32_t lo_bits;         // split of the two-level tables
+    uint32_t b_fast;          // 1: consecutive threads walk b first (column pass), 0: a first (row pass)
+};
+
+// FLAGS: 1 = pre-scale input by scale tables (coset_fft), 2 = twist output (pass 1 of 2),
+//        4 = post-scale by scale tables (coset_ifft), 8 = post-scale by constant, 16 = emit canonical output
+template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs A)
+{
+    extern __shared__ uint32_t lds[]; // [9][cols * S]
+    const uint32_t S = 1u << A.log_s, cols = A.cols, E = cols * S;
+    const uint32_t b0 = blockIdx.x * cols;
+    const uint32_t tid = threadIdx.x;
+
+    // ---- load (+ optional coset pre-scale), bit-reversed into LDS ------------------------------------------------
+    for (uint32_t e = tid; e < E; e += NTT_THREADS) {
+        uint32_t a, c;
+        if (A.b_fast) { c = e & (cols - 1); a = e >> A.log_cols; } else { a = e & (S - 1); c = e >> A.log_s; }
+        const size_t gidx = (size_t)a * A.in_sa + (size_t)(b0 + c) * A.in_sb;
+        uint32_t w[8];
+        load8(A.in + 8 * gidx, w);
+        FrL x = unpack<Fr>(w);
+        if constexpr (FLAGS & 1) {
+            const uint32_t i = (uint32_t)gidx; // natural coefficient index
+            auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
+            x = mul(x, g);
+        }
+        const uint32_t pos = c * S + bitrev(a, A.log_s);
+#pragma unroll
+        for (int l = 0; l < NL; l++) lds[l * E + pos] = x.d[l];
+    }
+    __syncthreads();
+
+    // ---- log_s radix-2 DIT stages in LDS ---------------------------------------------------------------------------
+    const uint32_t half = S >> 1, nbf = cols * half;
+    for (uint32_t s = 0; s < A.log_s; s++) {
+        const uint32_t m = 1u << s;
+        for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
+            const uint32_t c = bf >> (A.log_s - 1), i = bf & (half - 1);
+            const uint32_t j = i & (m - 1);
+            const uint32_t lo = c * S + (((i >> s) << (s + 1)) | j), hi = lo + m;
+            FrL x, y;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                x.d[l] = lds[l * E + lo];
+                y.d[l] = lds[l * E + hi];
+            }
+            if (s == 0) { // twiddle is one: x' = x + y, y' = x - y
+                FrL xs = assume_bound<1, NTT_VMAX>(weak(add(x, y)));
+                FrL ys = assume_bound<1, NTT_VMAX>(weak(sub(x, y)));
+                x = xs;
+                y = ys;
+            } else {
+                FeT<Fr> w = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
+                auto t = mul(w, y); // < 3p
+                FrL xs = assume_bound<1, NTT_VMAX>(weak(add(x, t)));
+                FrL ys = assume_bound<1, NTT_VMAX>(weak(sub(x, t)));
+                x = xs;
+                y = ys;
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                lds[l * E + lo] = x.d[l];
+                lds[l * E + hi] = y.d[l];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- store (+ twist / post-scale / canonicalise) ---------------------------------------------------------------
+    for (uint32_t e = tid; e < E; e += NTT_THREADS) {
+        uint32_t k, c;
+        if (A.b_fast) { c = e & (cols - 1); k = e >> A.log_cols; } else { k = e & (S - 1); c = e >> A.log_s; }
+        const uint32_t b = b0 + c;
+        FrL x;
+#pragma unroll
+        for (int l = 0; l < NL; l++) x.d[l] = lds[l * E + c * S + k];
+        const size_t gidx = (size_t)k * A.out_sa + (size_t)b * A.out_sb;
+        uint32_t w[8];
+        if constexpr (FLAGS & 2) {
+            const uint32_t ex = b * k; // < n
+            auto tw = mul(load_tw(A.twist_lo, ex & ((1u << A.lo_bits) - 1)), load_tw(A.twist_hi, ex >> A.lo_bits));
+            auto r = mul(x, tw); // 48 * 2 / 169 + 2 = 2  -> fits 256 bits
+            pack(r, w);
+        } else {
+            Fe<Fr, 1, 3> r;
+            if constexpr ((FLAGS & 4) && (FLAGS & 8)) {
+                const uint32_t i = (uint32_t)gidx;
+                auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
+                r = mul(mul(x, g), fe_from<Fr>(A.post_const));
+            } else if constexpr (FLAGS & 4) {
+                const uint32_t i = (uint32_t)gidx;
+                auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
+                r = mul(x, g);
+            } else if constexpr (FLAGS & 8) {
+                r = mul(x, fe_from<Fr>(A.post_const));
+            } else {
+                r = reduce_value(x);
+            }
+            to_canonical(r, w);
+        }
+        store8(A.out + 8 * gidx, w);
+    }
+}
+
+// table[k] = base^(k * stride_exp) * factor   (all Montgomery-261), k < count; canonical packed output
+__global__ void ntt_pow_table_kernel(uint32_t* table, uint32_t count, Limbs9 base, Limbs9 factor)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    Fe<Fr, 1, 2> acc = fe_from<Fr>(factor.d);
+    Fe<Fr, 1, 2> b = fe_from<Fr>(base.d);
+    for (uint32_t e = k; e; e >>= 1) {
+        if (e & 1) acc = mul(acc, b);
+        b = sqr(b);
+    }
+    uint32_t w[8];
+    to_canonical(acc, w);
+    store8(table + 8 * (size_t)k, w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// small host big-int helpers on the 9x29 representation (host-side product code, no oracle involved)
+using H = Fe<Fr, 1, 2>;
+H h_from(const uint32_t (&a)[NL]) { return fe_from<Fr>(a); }
+H h_pow2k(H a, int k) { for (int i = 0; i < k; i++) a = sqr(a); return a; }
+Limbs9 to_limbs(const H& a)
+{
+    // canonicalise so that device tables start from unique representatives
+    uint32_t w[8];
+    to_canonical(a, w);
+    Fe<Fr, 1, 6> u = unpack<Fr>(w);
+    Limbs9 r;
+    for (int i = 0; i < NL; i++) r.d[i] = u.d[i];
+    return r;
+}
+H h_inv(const H& a)
+{
+    uint64_t e[4] = { Fr::P64[0] - 2, Fr::P64[1], Fr::P64[2], Fr::P64[3] };
+    return pow_u256<Fr>(a, e);
+}
+
+struct DomainTables {
+    int log2n = -1;
+    int log_s1 = 0, log_s2 = 0, lo_bits = 0;
+    uint32_t* tw_sub[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } }; // [inverse][pass]
+    uint32_t* twist_lo[2] = { nullptr, nullptr };                            // [inverse]
+    uint32_t* twist_hi[2] = { nullptr, nullptr };
+    uint32_t* scale_lo[2] = { nullptr, nullptr };                            // [0]: g^i, [1]: g^-i * n^-1
+    uint32_t* scale_hi[2] = { nullptr, nullptr };
+    Limbs9 n_inv;                                                            // Montgomery-261
+};
+
+std::mutex g_mu;
+std::unordered_map<int, DomainTables*> g_domains; // keyed by device * 64 + log2n
+
+hipError_t pow_table(uint32_t** out, uint32_t count, const H& base, const H& factor, hipStream_t st)
+{
+    hipError_t e = hipMalloc((void**)out, (size_t)count * 32);
+    if (e != hipSuccess) return e;
+    ntt_pow_table_kernel<<<(count + 127) / 128, 128, 0, st>>>(*out, count, to_limbs(base), to_limbs(factor));
+    return hipGetLastError();
+}
+
+hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
+{
+    D->log2n = log2n;
+    // split: sub-transform sizes as balanced as possible, both <= 2^NTT_MAX_LOG_SUB
+    if (log2n <= NTT_MAX_LOG_SUB) {
+        D->log_s1 = log2n;
+        D->log_s2 = 0;
+    } else {
+        D->log_s2 = log2n / 2;
+        D->log_s1 = log2n - D->log_s2;
+    }
+    D->lo_bits = (log2n + 1) / 2;
+    const H one = fe_one<Fr>();
+    H root = h_pow2k(h_from(Fr::ROOT28), 28 - log2n);          // w_n   (field.hpp:487-494 semantics)
+    H root_inv = h_pow2k(h_from(Fr::ROOT28_INV), 28 - log2n);  // w_n^-1
+    // n^-1 = (2^-1)^log2n
+    H ninv = one;
+    {
+        H half = h_inv(weak(add(fe_one<Fr>(), fe_one<Fr>())));
+        for (int i = 0; i < log2n; i++) ninv = mul(ninv, half);
+    }
+    D->n_inv = to_limbs(ninv);
+    hipError_t e;
+    for (int inv = 0; inv < 2; inv++) {
+        const H w = inv ? root_inv : root;
+        // sub-transform twiddles: w_S = w_n^(n/S)
+        const int logs[2] = { D->log_s1, D->log_s2 };
+        for (int p = 0; p < 2; p++) {
+            if (logs[p] < 1) continue;
+            H ws = h_pow2k(w, log2n - logs[p]);
+            uint32_t cnt = logs[p] >= 1 ? (1u << (logs[p] - 1)) : 1;
+            if ((e = pow_table(&D->tw_sub[inv][p], cnt, ws, one, st)) != hipSuccess) return e;
+        }
+        if ((e = pow_table(&D->twist_lo[inv], 1u << D->lo_bits, w, one, st)) != hipSuccess) return e;
+        if ((e = pow_table(&D->twist_hi[inv], 1u << (log2n - D->lo_bits), h_pow2k(w, D->lo_bits), one, st)) != hipSuccess) return e;
+    }
+    // coset scale tables: [0] g^i ; [1] g^-i * n^-1   (generator 5: fr.hpp:66-74)
+    H g = h_from(Fr::GEN5), gi = h_from(Fr::GEN5_INV);
+    if ((e = pow_table(&D->scale_lo[0], 1u << D->lo_bits, g, one, st)) != hipSuccess) return e;
+    if ((e = pow_table(&D->scale_hi[0], 1u << (log2n - D->lo_bits), h_pow2k(g, D->lo_bits), one, st)) != hipSuccess) return e;
+    if ((e = pow_table(&D->scale_lo[1], 1u << D->lo_bits, gi, one, st)) != hipSuccess) return e;
+    if ((e = pow_table(&D->scale_hi[1], 1u << (log2n - D->lo_bits), h_pow2k(gi, D->lo_bits), ninv, st)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+hipError_t get_domain(int log2n, hipStream_t st, DomainTables** out)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_domains.find(dev * 64 + log2n);
+    if (it != g_domains.end()) {
+        *out = it->second;
+        return hipSuccess;
+    }
+    DomainTables* D = new DomainTables();
+    hipError_t e = build_domain(D, log2n, st);
+    if (e != hipSuccess) {
+        delete D;
+        return e;
+    }
+    g_domains[dev * 64 + log2n] = D;
+    *out = D;
+    return hipSuccess;
+}
+
+template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st)
+{
+    const uint32_t S = 1u << A.log_s, blocks = (1u << A.log_b) / A.cols;
+    const size_t lds = (size_t)A.cols * S * NL * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
+        attr_set = true;
+    }
+    ntt_pass_kernel<FLAGS><<<blocks, NTT_THREADS, lds, st>>>(A);
+    return hipGetLastError();
+}
+
+hipError_t dispatch(int flags, const NttPassArgs& A, hipStream_t st)
+{
+    switch (flags) {
+#define CASE(F) case F: return launch_pass<F>(A, st);
+        CASE(2) CASE(3)                                   // pass 1: twist, optionally pre-scaled
+        CASE(16) CASE(17) CASE(20) CASE(24) CASE(25) CASE(28) // last pass variants
+#undef CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace
+
+// kind: bbgpu_ntt_kind; d_coeffs: n x 32 B device buffer, transformed in place; d_scratch: n x 32 B (only n > 2^11)
+int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256, hipStream_t st)
+{
+    if (log2n < 1 || log2n > 2 * NTT_MAX_LOG_SUB) return BBGPU_ERR_SIZE;
+    DomainTables* D;
+    if (get_domain(log2n, st, &D) != hipSuccess) return BBGPU_ERR_HIP;
+    const bool inverse = (kind == BBGPU_IFFT || kind == BBGPU_COSET_IFFT || kind == BBGPU_IFFT_WITH_CONSTANT);
+    const bool pre = (kind == BBGPU_COSET_FFT || kind == BBGPU_COSET_FFT_WITH_CONSTANT);
+    const bool post_table = (kind == BBGPU_COSET_IFFT);
+    const bool has_const = (kind == BBGPU_FFT_WITH_CONSTANT || kind == BBGPU_IFFT_WITH_CONSTANT || kind == BBGPU_COSET_FFT_WITH_CONSTANT);
+    if (has_const && !constant_m256) return BBGPU_ERR_ARG;
+
+    // constant applied at the last store (Montgomery-261): c (converted from the caller's 2^256 form), times n^-1 for
+    // ifft; coset_ifft gets its n^-1 from the scale_hi table
+    bool post_const = false;
+    H pc = fe_one<Fr>();
+    if (has_const) {
+        uint32_t w[8];
+        for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)constant_m256[i]; w[2 * i + 1] = (uint32_t)(constant_m256[i] >> 32); }
+        pc = m256_to_m261<Fr>(unpack<Fr>(w));
+        post_const = true;
+    }
+    if (kind == BBGPU_IFFT || kind == BBGPU_IFFT_WITH_CONSTANT) {
+        pc = mul(pc, fe_from<Fr>(D->n_inv.d));
+        post_const = true;
+    }
+    const Limbs9 pcl = to_limbs(pc);
+
+    const uint32_t n1 = 1u << D->log_s1, n2 = 1u << D->log_s2;
+    NttPassArgs A{};
+    A.lo_bits = D->lo_bits;
+    A.twist_lo = D->twist_lo[inverse];
+    A.twist_hi = D->twist_hi[inverse];
+    A.scale_lo = D->scale_lo[post_table ? 1 : 0];
+    A.scale_hi = D->scale_hi[post_table ? 1 : 0];
+    for (int i = 0; i < NL; i++) A.post_const[i] = pcl.d[i];
+    const int last_flags = 16 | (post_table ? 4 : 0) | (post_const ? 8 : 0);
+    hipError_t e;
+    if (D->log_s2 == 0) { // single pass, everything in one workgroup's LDS
+        A.in = (const uint32_t*)d_coeffs;
+        A.out = (uint32_t*)d_coeffs;
+        A.tw_sub = D->tw_sub[inverse][0];
+        A.log_s = D->log_s1; A.log_b = 0; A.cols = 1; A.log_cols = 0;
+        A.in_sa = 1; A.in_sb = 0; A.out_sa = 1; A.out_sb = 0; A.b_fast = 0;
+        e = dispatch(last_flags | (pre ? 1 : 0), A, st);
+        return e == hipSuccess ? BBGPU_OK : BBGPU_ERR_HIP;
+    }
+    if (!d_scratch) return BBGPU_ERR_ARG;
+    // pass 1: columns (a = j1, b = j2), coeffs -> scratch, same layout
+    A.in = (const uint32_t*)d_coeffs;
+    A.out = (uint32_t*)d_scratch;
+    A.tw_sub = D->tw_sub[inverse][0];
+    A.log_s = D->log_s1; A.log_b = D->log_s2;
+    A.cols = NTT_LDS_ELEMS >> D->log_s1; if (A.cols > n2) A.cols = n2;
+    A.log_cols = 31 - __builtin_clz(A.cols);
+    A.in_sa = n2; A.in_sb = 1; A.out_sa = n2; A.out_sb = 1; A.b_fast = 1;
+    if ((e = dispatch(2 | (pre ? 1 : 0), A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    // pass 2: rows (a = j2, b = k1), scratch -> coeffs transposed: X[k1 + n1 * k2]
+    A.in = (const uint32_t*)d_scratch;
+    A.out = (uint32_t*)d_coeffs;
+    A.tw_sub = D->tw_sub[inverse][1];
+    A.log_s = D->log_s2; A.log_b = D->log_s1;
+    A.cols = NTT_LDS_ELEMS >> D->log_s2; if (A.cols > n1) A.cols = n1;
+    A.log_cols = 31 - __builtin_clz(A.cols);
+    A.in_sa = 1; A.in_sb = n2; A.out_sa = n1; A.out_sb = 1; A.b_fast = 0;
+    if ((e = dispatch(last_flags, A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    return BBGPU_OK;
+}
+
+void ntt_release_tables()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_domains) {
+        DomainTables* D = kv.second;
+        for (int i = 0; i < 2; i++) {
+            for (int p = 0; p < 2; p++) if (D->tw_sub[i][p]) (void)hipFree(D->tw_sub[i][p]);
+            if (D->twist_lo[i]) (void)hipFree(D->twist_lo[i]);
+            if (D->twist_hi[i]) (void)hipFree(D->twist_hi[i]);
+            if (D->scale_lo[i]) (void)hipFree(D->scale_lo[i]);
+            if (D->scale_hi[i]) (void)hipFree(D->scale_hi[i]);
+        }
+        delete D;
+    }
+    g_domains.clear();
+}
+
+} // namespace bbgpu

@@ -1,0 +1,109 @@
+/*
+ * bbgpu.h -- C ABI of libbbgpu.so: MI355X (gfx950) implementations of barretenberg's PLONK-prover hot path,
+ * BN254 G1 Pippenger MSM and radix-2 NTT / coset-FFT over Fr.
+ *
+ * Every entry point names the reference interface it replaces (paths under /root/reference/src/barretenberg/).
+ * Conventions are the reference's own:
+ *   field element   = 4 x uint64_t little-endian limbs, Montgomery form (x * 2^256 mod p)      fields/field.hpp:19-22
+ *   affine G1 point = {x, y} = 8 x uint64_t; Jacobian = {x, y, z} = 12 x uint64_t               groups/group.hpp:17-28
+ *   point at infinity <=> bit 63 of y limb 3                                                    groups/group.hpp:133-151
+ *   scalars may be any representative in [0, 2r); NTT inputs in [0, 2^256); NTT outputs canonical [0, r)
+ *   MSM results are returned NORMALISED: z = fq::one, x,y canonical (what batched_scalar_multiplications hands the
+ *   prover, scalar_multiplication.cpp:765; any Jacobian representative is legal for pippenger(), :457-476)
+ * All functions return BBGPU_OK (0) or a negative error code; bbgpu_last_error() describes the last failure of the
+ * calling thread.  There is NO CPU fallback inside this library: if no GPU / no code object, calls fail loudly.
+ */
+#ifndef BBGPU_H
+#define BBGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    BBGPU_OK = 0,
+    BBGPU_ERR_HIP = -1,   /* a HIP runtime call failed (no device, out of memory, launch failure) */
+    BBGPU_ERR_SIZE = -2,  /* size not supported (NTT: n must be 2^k, 2 <= n <= 2^22) */
+    BBGPU_ERR_ARG = -3,   /* null pointer / bad enum / unknown handle */
+    BBGPU_ERR_STATE = -4  /* library not initialised */
+};
+
+/* polynomial_arithmetic.hpp:27-41: which member of the fft family */
+typedef enum {
+    BBGPU_FFT = 0,                     /* fft()                      polynomial_arithmetic.cpp:266 */
+    BBGPU_IFFT = 1,                    /* ifft()                     :271-277 */
+    BBGPU_COSET_FFT = 2,               /* coset_fft()                :287-291 */
+    BBGPU_COSET_IFFT = 3,              /* coset_ifft()               :311-315 */
+    BBGPU_FFT_WITH_CONSTANT = 4,       /* fft_with_constant()        :279-285 */
+    BBGPU_IFFT_WITH_CONSTANT = 5,      /* ifft_with_constant()       :301-309 */
+    BBGPU_COSET_FFT_WITH_CONSTANT = 6  /* coset_fft_with_constant()  :293-299 */
+} bbgpu_ntt_kind;
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------------- */
+int bbgpu_init(int device);       /* binds the calling process to one GPU (one process per GPU), allocates workspaces */
+void bbgpu_shutdown(void);
+int bbgpu_device_count(void);
+const char* bbgpu_last_error(void);
+const char* bbgpu_version(void);
+
+/* ---- NTT ---------------------------------------------------------------------------------------------------------
+ * Drop-in for polynomial_arithmetic::{fft,ifft,coset_fft,coset_ifft,fft_with_constant,ifft_with_constant,
+ * coset_fft_with_constant}(fr::field_t* coeffs, const evaluation_domain& domain[, const fr::field_t& constant]):
+ * transforms coeffs[0..n) in place.  `constant` (4 limbs, Montgomery) is read for the *_with_constant kinds only.
+ * bbgpu_ntt: host buffer (copied to the device and back).  bbgpu_ntt_device: device-resident buffer, asynchronous on
+ * `hip_stream` (a hipStream_t, may be NULL for the default stream). */
+int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant);
+int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* constant, void* hip_stream);
+
+/* ---- MSM ---------------------------------------------------------------------------------------------------------
+ * The prover passes the same SRS to every MSM (reference_string.cpp:16-35), laid out as the 2n-entry endomorphism
+ * table of generate_pippenger_point_table (scalar_multiplication.cpp:131-140): entry 2i = P_i, entry 2i+1 = (beta x_i,
+ * -y_i).  bbgpu_srs_register uploads the n base points (even entries) once and keeps them resident on the GPU in the
+ * kernels' working form; it returns a handle >= 0.  Host-pointer MSM calls look the table up by address (and register
+ * it on first sight), so sub-slices `points + 2*off` of a registered table are served from the resident copy
+ * (batched_scalar_multiplications slices exactly like that, scalar_multiplication.cpp:720-726). */
+int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
+int bbgpu_srs_release(int handle);
+/* device-side generation of the synthetic SRS x^i * G, i < n, straight into a resident table; optionally also written
+ * back to the host as the reference-format 2n endo table (may be NULL).  Stands in for the missing srs_db/transcript.dat */
+int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out);
+
+/* drop-in for scalar_multiplication::pippenger(scalars, points, n, bucket_width) (:457-476); scalars not modified.
+ * out = {x, y, z} normalised, or infinity flag set (n == 0, all-zero scalars). */
+int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12]);
+
+/* drop-in for scalar_multiplication::batched_scalar_multiplications(mul_state, num) (:650-772); layout-identical to
+ * multiplication_state (scalar_multiplication.hpp:88-94: points@0, scalars@8, num_elements@16, output@32, size 128) */
+typedef struct {
+    const uint64_t* points;  /* 2n-entry endo table */
+    const uint64_t* scalars; /* n scalars */
+    size_t num_elements;
+    uint64_t _pad;
+    uint64_t output[12]; /* written normalised */
+} bbgpu_msm_job;
+int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs);
+
+/* scalars already resident in HBM (n x 4 limbs), points = a registered SRS handle (first n points, starting at
+ * point `offset`).  Windows [window_begin, window_end) of the signed-digit decomposition are processed -- the whole
+ * scalar is windows [0, bbgpu_msm_num_windows(n)).  The result is the partial sum over those windows, normalised; partial
+ * sums of disjoint window ranges add up to the full MSM (bbgpu_g1_sum).  This is the multi-GPU entry: rank g takes its
+ * share of the windows, partial sums are exchanged (RCCL all-gather of 96 bytes per rank) and folded on every rank. */
+int bbgpu_msm_num_windows(size_t n);
+int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
+                        int window_end, uint64_t out[12], void* hip_stream);
+/* out = sum of `count` normalised/Jacobian points (infinity flags honoured), normalised.  Host arithmetic. */
+int bbgpu_g1_sum(const uint64_t* points12, size_t count, uint64_t out[12]);
+
+/* ---- instrumentation (bench.py) ---------------------------------------------------------------------------------
+ * Device time in milliseconds of the kernels launched by the most recent bbgpu_*_device call on this thread, measured
+ * with hipEvents on the stream the kernels ran on.  index: 0 = total, then per stage. */
+int bbgpu_last_timing(float* ms_out, int max_entries);
+void bbgpu_set_timing(int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBGPU_H */

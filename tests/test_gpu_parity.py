@@ -1,0 +1,253 @@
+"""GPU parity tests (-m gpu): libbbgpu.so through its C ABI vs the oracle and the reference-generated fixtures.
+Bit-exact bar: integer work, no tolerance."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FQ, FR, FR_MODULUS, NTT_KINDS, aligned_copy
+from tests.util import CONST_SEED, NTT_SEED, SCALAR_SEED, SRS_SEED, limbs, noncanonical, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from barretenberg_amd import BbGpu
+    g = BbGpu(device=0)
+    yield g
+    g.shutdown()
+
+
+@pytest.fixture(scope="module")
+def const(oracle):
+    return oracle.random_scalars(CONST_SEED, 1)[0]
+
+
+# ------------------------------------------------------------------ NTT ----------------------------------------------
+@pytest.mark.parametrize("log2n", [1, 2, 3, 4, 5, 8, 10, 11, 12, 13])
+def test_ntt_vs_oracle_all_kinds(gpu, oracle, const, log2n):
+    n = 1 << log2n
+    co = noncanonical(oracle.random_scalars(NTT_SEED + log2n, n), FR_MODULUS)
+    for kind in NTT_KINDS:
+        want = oracle.ntt(co, kind, const)
+        got = gpu.ntt(co.copy(), kind, const)
+        assert np.array_equal(got, want), (log2n, kind)
+
+
+def test_ntt_golden_small(gpu, golden):
+    g = golden("ntt.json")
+    c = limbs(g["constant"])
+    for case in g["small"]:
+        co = limbs(case["input"]).reshape(-1, 4)
+        got = gpu.ntt(co.copy(), case["kind"], c)
+        assert np.array_equal(got.reshape(-1), limbs(case["output"])), (case["n"], case["kind"])
+
+
+@pytest.mark.parametrize("log2n", [8, 10, 12, 16, 20, 22])
+def test_ntt_golden_digests(gpu, oracle, golden, log2n):
+    """outputs of the reference itself (oracle/_ref) at BASELINE sizes 2^20 and 4*2^20: sha256 + sampled elements"""
+    g = golden("ntt.json")
+    c = limbs(g["constant"])
+    n = 1 << log2n
+    co = noncanonical(oracle.random_scalars(NTT_SEED, n), FR_MODULUS)
+    for case in [x for x in g["large"] if x["n"] == n]:
+        got = gpu.ntt(co.copy(), case["kind"], c)
+        for i, v in case["samples"].items():
+            assert np.array_equal(got[int(i)], limbs(v)), (log2n, case["kind"], i)
+        assert sha(got) == case["sha256"], (log2n, case["kind"])
+
+
+def test_ntt_fft_matches_direct_evaluation(gpu, oracle):
+    """test_polynomial_arithmetic.cpp:31-56"""
+    n = 16
+    poly = oracle.random_scalars(4242, n)
+    out = gpu.fft(poly.copy())
+    root = oracle.root_of_unity(4)
+    w = oracle.const(FR, "one")
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.evaluate(poly, w))
+        w = oracle.mul(FR, w, root)
+
+
+@pytest.mark.parametrize("log2n", [14, 20, 22])
+def test_ntt_roundtrips_full_size(gpu, oracle, log2n):
+    """test_polynomial_arithmetic.cpp:58-128 at BASELINE sizes: ifft(fft(x)) == x, coset_ifft(coset_fft(x)) == x"""
+    n = 1 << log2n
+    x = oracle.random_scalars(99 + log2n, n)  # canonical
+    y = gpu.ifft(gpu.fft(x.copy()))
+    assert np.array_equal(x, y)
+    y = gpu.coset_ifft(gpu.coset_fft(x.copy()))
+    assert np.array_equal(x, y)
+
+
+def test_ntt_cross_domain_coset_consistency(gpu, oracle):
+    """test_polynomial_arithmetic.cpp:130-175: coset FFTs of one polynomial on n, 2n, 4n agree on shared points"""
+    n = 1 << 10
+    base = oracle.random_scalars(777, n)
+    outs = []
+    for mult in (1, 2, 4):
+        buf = np.zeros((mult * n, 4), dtype=np.uint64)
+        buf[:n] = base
+        outs.append(gpu.coset_fft(buf))
+    assert np.array_equal(outs[0], outs[1][::2]) and np.array_equal(outs[0], outs[2][::4])
+
+
+def test_ntt_linearity_full_size(gpu, oracle):
+    n = 1 << 20
+    a = oracle.random_scalars(1, n)
+    b = oracle.random_scalars(2, n)
+    # a + b mod r, vectorised on limbs via python ints would be slow: use fft(a)+fft(b) check on samples instead
+    fa, fb = gpu.fft(a.copy()), gpu.fft(b.copy())
+    s = np.stack([oracle.add(FR, a[i], b[i]) for i in range(0, n, 1 << 12)])
+    full = a.copy()
+    for k, i in enumerate(range(0, n, 1 << 12)):
+        full[i] = s[k]
+    # sparse difference d = full - a is non-zero only at stride 2^12 => fft(full) - fft(a) == fft(d)
+    d = np.zeros_like(a)
+    for k, i in enumerate(range(0, n, 1 << 12)):
+        d[i] = b[i]
+    fd, ff = gpu.fft(d.copy()), gpu.fft(full.copy())
+    for i in (0, 1, 12345, n - 1):
+        assert np.array_equal(ff[i], oracle.add(FR, fa[i], fd[i]))
+
+
+def test_ntt_rejects_bad_sizes(gpu):
+    from barretenberg_amd import BbGpuError
+    with pytest.raises(BbGpuError):
+        gpu.fft(np.zeros((3, 4), dtype=np.uint64))
+    with pytest.raises(BbGpuError):
+        gpu.fft(np.zeros((1, 4), dtype=np.uint64))
+
+
+# ------------------------------------------------------------------ MSM ----------------------------------------------
+@pytest.fixture(scope="module")
+def msm_small(oracle, golden):
+    g = golden("msm.json")
+    x = limbs(g["srs_secret_mont"])
+    n = 1 << 16
+    srs = oracle.make_srs(x, n)
+    assert sha(srs) == g["srs_digest_65536"]
+    table = oracle.point_table(srs)
+    scalars = oracle.random_scalars(SCALAR_SEED, n)
+    return g, srs, table, scalars
+
+
+def _check(out, case):
+    if "infinity" in case:
+        assert bool(int(out[7]) >> 63) == case["infinity"]
+    else:
+        assert np.array_equal(out[0:4], limbs(case["x"])) and np.array_equal(out[4:8], limbs(case["y"])), case
+        assert not (int(out[7]) >> 63)
+
+
+def test_msm_golden(gpu, oracle, msm_small):
+    """normalised results of the reference's pippenger()/batched_scalar_multiplications() on the same inputs"""
+    g, srs, table, scalars = msm_small
+    one = oracle.const(FQ, "one")
+    done = 0
+    for case in g["cases"]:
+        n = case["n"]
+        if n > (1 << 16) or "scalars" in case or "points" in case:
+            continue
+        out = gpu.pippenger(scalars, table, n)
+        _check(out, case)
+        if "x" in case:
+            assert np.array_equal(out[8:12], one)
+        done += 1
+    assert done >= 12
+
+
+def test_msm_edge_cases(gpu, oracle, msm_small):
+    g, srs, table, scalars = msm_small
+    for case in g["cases"]:
+        if case.get("scalars") == "even-index scalars zero":
+            zs = scalars[:64].copy()
+            zs[::2] = 0
+            _check(gpu.pippenger(aligned_copy(zs), table, 64), case)
+        elif case.get("scalars") == "all zero":
+            _check(gpu.pippenger(aligned_copy(np.zeros((16, 4), dtype=np.uint64)), table, 16), case)
+        elif case["n"] == 0:
+            _check(gpu.pippenger(scalars, table, 0), case)
+        elif "points" in case:
+            same_t = oracle.point_table(aligned_copy(np.tile(srs[5], (32, 1))))
+            sc = aligned_copy(np.tile(oracle.const(FR, "one"), (32, 1))) if case.get("scalars") == "all one" else scalars
+            _check(gpu.pippenger(sc, same_t, 32), case)
+
+
+def test_msm_noncanonical_scalars(gpu, oracle, msm_small):
+    """scalars in [r, 2r) (kate coefficients, polynomial_arithmetic.cpp:580-588) give the same point"""
+    g, srs, table, scalars = msm_small
+    n = 1000
+    sc = noncanonical(scalars[:n], FR_MODULUS)
+    case = [c for c in g["cases"] if c["n"] == 1000][0]
+    _check(gpu.pippenger(aligned_copy(sc), table, n), case)
+
+
+def test_msm_batched(gpu, oracle, msm_small):
+    """scalar_multiplication.cpp:650-772 / test_scalar_multiplication.cpp:271-324"""
+    g, srs, table, scalars = msm_small
+    big = oracle.random_scalars(SCALAR_SEED, 3 * 4096)
+    jobs = [(table, aligned_copy(big[o:o + 4096]), 4096) for o in (0, 4096, 8192)]
+    outs = gpu.batched_scalar_multiplications(jobs)
+    for out, want in zip(outs, g["batched_3x4096"]):
+        assert np.array_equal(out[0:4], limbs(want["x"])) and np.array_equal(out[4:8], limbs(want["y"]))
+        assert np.array_equal(out[8:12], limbs(want["z"]))
+    from barretenberg_amd import BbGpuError
+    with pytest.raises(BbGpuError):
+        gpu.batched_scalar_multiplications([(table, scalars, 8), (table, scalars, 9)])
+
+
+def test_msm_subslice_of_registered_table(gpu, oracle, msm_small):
+    """batched_scalar_multiplications hands pippenger sub-slices points + 2*off of one table (:720-726)"""
+    g, srs, table, scalars = msm_small
+    off, n = 100, 300
+    want = oracle.msm_affine(aligned_copy(scalars[off:off + n]), aligned_copy(table[2 * off:2 * (off + n)]), n)
+    h = gpu.srs_register(table)
+    got = gpu.pippenger(aligned_copy(scalars[off:off + n]), table[2 * off:], n)
+    assert np.array_equal(got[:8], want[:8])
+    assert gpu.srs_register(table) == h
+
+
+def test_msm_vs_oracle_random_sizes(gpu, oracle, msm_small):
+    g, srs, table, scalars = msm_small
+    for n in (5, 31, 257, 2048):
+        want = oracle.msm_affine(scalars, table, n)
+        assert np.array_equal(gpu.pippenger(scalars, table, n)[:8], want[:8]), n
+
+
+def test_msm_window_sharding_adds_up(gpu, oracle, msm_small):
+    """multi-GPU path on one device: partial sums over disjoint window ranges fold to the full MSM (bbgpu_g1_sum)"""
+    import torch
+    g, srs, table, scalars = msm_small
+    n = 1 << 14
+    h = gpu.srs_register(table)
+    d_sc = torch.from_numpy(scalars[:n].view(np.int64)).cuda()
+    W = gpu.msm_num_windows(n)
+    full = gpu.msm_device(h, d_sc.data_ptr(), n)
+    want = oracle.msm_affine(scalars, table, n)
+    assert np.array_equal(full[:8], want[:8])
+    for parts in (2, 4, 8):
+        bounds = [W * r // parts for r in range(parts + 1)]
+        partials = [gpu.msm_device(h, d_sc.data_ptr(), n, 0, bounds[r], bounds[r + 1]) for r in range(parts) if bounds[r] < bounds[r + 1]]
+        assert np.array_equal(gpu.g1_sum(np.stack(partials)), full), parts
+
+
+def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
+    """BASELINE config 2: 2^20-point MSM, random scalars vs the synthetic SRS; expected point from the reference."""
+    import torch
+    g = golden("msm.json")
+    n = 1 << 20
+    x = limbs(g["srs_secret_mont"])
+    h, table = gpu.srs_generate(x, n, want_host_table=True)
+    for i, v in g["srs_samples"].items():
+        assert np.array_equal(table[2 * int(i)], limbs(v))
+    assert sha(table[0:2 * 65536:2]) == g["srs_digest_65536"]
+    assert sha(table[0::2]) == g["srs_digest_1048576"]
+    assert sha(table[:8192]) == g["table_digest_4096"]  # endo entries too
+    scalars = oracle.random_scalars(SCALAR_SEED, n)
+    d_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
+    out = gpu.msm_device(h, d_sc.data_ptr(), n)
+    case = [c for c in g["cases"] if c["n"] == n][0]
+    _check(out, case)
+    # host-pointer path resolves to the same resident table
+    out2 = gpu.pippenger(scalars, table, n)
+    assert np.array_equal(out, out2)

@@ -1,0 +1,95 @@
+"""CPU tests of the drop-in boundary: library loads, exports every symbol include/bbgpu.h declares, fails loudly
+without a GPU, and the host-side tail arithmetic (bbgpu_g1_sum, no GPU needed) matches the oracle."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from barretenberg_amd import BbGpu, build_library
+    build_library()
+    return BbGpu(init=False)
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "bbgpu.h")).read()
+    declared = set(re.findall(r"\b(bbgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"bbgpu_msm_job"}
+    from barretenberg_amd.bbgpu import C_ABI_SYMBOLS
+    assert declared == set(C_ABI_SYMBOLS), declared ^ set(C_ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib.lib, name), name
+
+
+def test_no_torch_types_in_abi():
+    hdr = open(os.path.join(ROOT, "include", "bbgpu.h")).read()
+    assert "torch" not in hdr and "at::" not in hdr and "std::" not in hdr
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from barretenberg_amd import BbGpuError
+    with pytest.raises(BbGpuError, match="no HIP device"):
+        lib.fft(np.zeros((4, 4), dtype=np.uint64))
+    with pytest.raises(BbGpuError):
+        lib.pippenger(np.zeros((4, 4), dtype=np.uint64), np.zeros((8, 8), dtype=np.uint64), 4)
+
+
+def test_product_does_not_import_oracle():
+    """the product path may not route through oracle/ (SURVEY scope rule 3)"""
+    pkg = os.path.join(ROOT, "barretenberg_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".hpp", ".cpp", "Makefile")):
+                text = open(os.path.join(dp, f)).read()
+                assert "pyoracle" not in text and "bn254_oracle" not in text and "liboracle" not in text and "_ref/" not in text, f
+
+
+def test_g1_sum_matches_oracle(lib, oracle):
+    one = oracle.g1_one_affine()
+    pts = [oracle.g1_scalar_mul(one, s) for s in oracle.random_scalars(2024, 6)]
+    acc = np.zeros(12, dtype=np.uint64)
+    acc[7] = np.uint64(1 << 63)
+    for p in pts:
+        acc = oracle.g1_add(acc, p)
+    want = oracle.g1_normalize(acc)
+    got = lib.g1_sum(np.stack(pts))
+    assert np.array_equal(got, want)
+    # Jacobian (non-normalised) inputs, infinity entries, P + (-P), P + P
+    from oracle.pyoracle import FQ
+    d = oracle.g1_dbl(pts[0])
+    inf = np.zeros(12, dtype=np.uint64)
+    inf[7] = np.uint64(1 << 63)
+    neg = pts[1].copy()
+    neg[4:8] = oracle.neg(FQ, pts[1][4:8])
+    got = lib.g1_sum(np.stack([d, inf, pts[1], neg, pts[2], pts[2]]))
+    want = oracle.g1_normalize(oracle.g1_add(d, oracle.g1_dbl(pts[2])))
+    assert np.array_equal(got, want)
+    assert int(lib.g1_sum(np.stack([pts[3], _neg(oracle, pts[3])]))[7]) >> 63 == 1
+    assert int(lib.g1_sum(np.zeros((0, 12), dtype=np.uint64))[7]) >> 63 == 1
+
+
+def _neg(oracle, p):
+    from oracle.pyoracle import FQ
+    q = p.copy()
+    q[4:8] = oracle.neg(FQ, p[4:8])
+    return q
+
+
+def test_host_field_code_matches_oracle():
+    """fe.cuh / g1.cuh (the code the kernels run) compiled for the host and checked against the oracle"""
+    exe = "/tmp/bbgpu_test_fe_host"
+    src = os.path.join(ROOT, "tests", "cpp", "test_fe_host.cpp")
+    ob = os.path.join(ROOT, "oracle", "_build")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, src, "-L" + ob, "-loracle", "-Wl,-rpath," + ob], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:]
