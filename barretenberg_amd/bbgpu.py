@@ -13,6 +13,11 @@ import subprocess
 
 import numpy as np
 
+try:  # plumbing: when torch is around, let it load ITS HIP runtime first so that device pointers handed over from torch
+    import torch  # noqa: F401  tensors and libbbgpu.so share one runtime (two runtimes in one process cannot both see the GPU)
+except Exception:  # pragma: no cover - torch is optional for the library itself
+    torch = None
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 u64p = C.POINTER(C.c_uint64)
 

@@ -237,21 +237,36 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_hist_kernel(const int16_t* _
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) out[b] = lh[b];
 }
 
-// K2: per window: bucket starts (exclusive scan over buckets of the per-bucket totals) and per-slice cursors (in place)
-__global__ void __launch_bounds__(SORT_THREADS) msm_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bstart, uint32_t nb, uint32_t slices)
+// K2a: for every (window, bucket) column: exclusive prefix over slices in place (cursors relative to the bucket start)
+// and the bucket's total.  One lane per bucket -> coalesced across lanes, nw * nb lanes.
+__global__ void __launch_bounds__(MSM_THREADS) msm_colscan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ gstart, uint32_t nb,
+                                                                uint32_t slices, uint32_t total_buckets)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_buckets) return;
+    const uint32_t wl = t / nb, b = t - wl * nb;
+    uint32_t* H = hist + (size_t)wl * slices * nb + b;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < slices; s++) {
+        const uint32_t cnt = H[(size_t)s * nb];
+        H[(size_t)s * nb] = run;
+        run += cnt;
+    }
+    gstart[t] = run; // bucket size for now
+}
+// K2b: per window: exclusive scan of the bucket sizes -> local bucket starts, and the window's entry count
+__global__ void __launch_bounds__(SORT_THREADS) msm_scan_kernel(uint32_t* __restrict__ gstart, uint32_t* __restrict__ totals, uint32_t nb)
 {
     __shared__ uint32_t part[SORT_THREADS];
     const uint32_t wl = blockIdx.x, t = threadIdx.x;
-    uint32_t* H = hist + (size_t)wl * slices * nb;
+    uint32_t* G = gstart + (size_t)wl * nb;
     const uint32_t per = (nb + SORT_THREADS - 1) / SORT_THREADS;
-    const uint32_t b0 = t * per, b1 = min(nb, b0 + per);
+    const uint32_t b0 = min(nb, t * per), b1 = min(nb, b0 + per);
     uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++)
-        for (uint32_t s = 0; s < slices; s++) sum += H[(size_t)s * nb + b];
+    for (uint32_t b = b0; b < b1; b++) sum += G[b];
     part[t] = sum;
     __syncthreads();
-    // exclusive scan of part[] (Hillis-Steele, 1024 entries)
-    for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
+    for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) { // inclusive Hillis-Steele scan
         uint32_t v = t >= off ? part[t - off] : 0;
         __syncthreads();
         part[t] += v;
@@ -259,64 +274,185 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_scan_kernel(uint32_t* __rest
     }
     uint32_t run = part[t] - sum;
     for (uint32_t b = b0; b < b1; b++) {
-        bstart[(size_t)wl * (nb + 1) + b] = run;
-        for (uint32_t s = 0; s < slices; s++) {
-            const uint32_t cnt = H[(size_t)s * nb + b];
-            H[(size_t)s * nb + b] = run;
-            run += cnt;
-        }
+        const uint32_t cnt = G[b];
+        G[b] = run;
+        run += cnt;
     }
-    if (t == SORT_THREADS - 1) bstart[(size_t)wl * (nb + 1) + nb] = part[SORT_THREADS - 1];
+    if (t == SORT_THREADS - 1) totals[wl] = part[SORT_THREADS - 1];
+}
+// K2c: make the bucket starts global (entries of all windows form one compact sorted list); bases[w] for the scatter
+__global__ void __launch_bounds__(SORT_THREADS) msm_bases_kernel(uint32_t* __restrict__ gstart, const uint32_t* __restrict__ totals,
+                                                               uint32_t* __restrict__ bases, uint32_t nb, uint32_t nw)
+{
+    const uint32_t wl = blockIdx.x;
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wl; w++) base += totals[w];
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) gstart[(size_t)wl * nb + b] += base;
+    if (threadIdx.x == 0) {
+        bases[wl] = base;
+        if (wl == nw - 1) gstart[(size_t)nw * nb] = base + totals[wl]; // M = total number of entries
+    }
 }
 
 __global__ void __launch_bounds__(SORT_THREADS) msm_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursors,
-                                                                 uint32_t* __restrict__ sorted, uint32_t n, uint32_t nb, uint32_t slices,
-                                                                 uint32_t slice_len, uint32_t win0)
+                                                                 const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ bases,
+                                                                 uint32_t* __restrict__ sorted,
+                                                                 uint32_t n, uint32_t nb, uint32_t slices, uint32_t slice_len, uint32_t win0)
 {
     extern __shared__ uint32_t lc[];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
     const uint32_t* cur = cursors + ((size_t)wl * slices + s) * nb;
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) lc[b] = cur[b];
+    (void)bases;
+    const uint32_t* gs = gstart + (size_t)wl * nb; // already global (K2c)
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) lc[b] = cur[b] + gs[b];
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
     const int16_t* dg = digits + (size_t)(win0 + wl) * n;
-    uint32_t* out = sorted + (size_t)wl * n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         const int d = dg[i];
         if (d) {
             const uint32_t pos = atomicAdd(&lc[(d < 0 ? -d : d) - 1], 1u);
-            out[pos] = i | (d < 0 ? 0x80000000u : 0u);
+            sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K4: bucket accumulation -- the hot loop (replaces scalar_multiplication.cpp:604-617)
+//   The sorted entry list (all windows, ordered by bucket) is cut into chunks of exactly `ch` entries, one lane per
+//   chunk, so every lane performs the same number of mixed additions whatever the digit distribution (the top window
+//   of 252..254-bit scalars touches only a fraction of its buckets, and real witnesses are skewed).  A lane walks its
+//   chunk with an XYZZ accumulator in VGPRs and flushes a partial sum whenever the bucket changes; partial (b, t) of
+//   bucket b and chunk t lands in slot b + t, which is injective and keeps each bucket's partials contiguous.
+//   K4m then adds the 1-3 partials of every bucket.
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_raw(uint32_t* dst, const Xyzz& p)
+{
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        dst[i] = p.x.d[i];
+        dst[NL + i] = p.y.d[i];
+        dst[2 * NL + i] = p.zz.d[i];
+        dst[3 * NL + i] = p.zzz.d[i];
+    }
+}
+__device__ __forceinline__ void load_raw(Xyzz& p, const uint32_t* src)
+{
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        p.x.d[i] = src[i];
+        p.y.d[i] = src[NL + i];
+        p.zz.d[i] = src[2 * NL + i];
+        p.zzz.d[i] = src[3 * NL + i];
+    }
+}
+constexpr int RAW_WORDS = 4 * NL; // 36 words per partial: lazy limbs, no canonicalisation on the hot path
+
 __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
-                                                                   const uint32_t* __restrict__ bstart, uint32_t* __restrict__ buckets,
-                                                                   uint32_t n, uint32_t nb, uint32_t total_buckets)
+                                                                   const uint32_t* __restrict__ gstart, uint32_t* __restrict__ partials,
+                                                                   uint32_t total_buckets, uint32_t ch)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_buckets) return;
-    const uint32_t wl = t / nb, b = t - wl * nb;
-    const uint32_t* bs = bstart + (size_t)wl * (nb + 1);
-    uint32_t e = bs[b];
-    const uint32_t end = bs[b + 1];
-    const uint32_t* ent = sorted + (size_t)wl * n;
+    const uint32_t M = gstart[total_buckets];
+    const uint32_t p0 = t * ch;
+    if (p0 >= M) return;
+    const uint32_t p1 = min(M, p0 + ch);
+    // bucket containing entry p0: last b with gstart[b] <= p0
+    uint32_t lo = 0, hi = total_buckets; // invariant: gstart[lo] <= p0 < gstart[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (gstart[mid] <= p0) lo = mid; else hi = mid;
+    }
+    uint32_t b = lo;
+    uint32_t next_end = gstart[b + 1];
     Xyzz acc;
     set_infinity(acc);
-    for (; e < end; e++) {
-        const uint32_t v = ent[e];
+    for (uint32_t e = p0; e < p1; e++) {
+        if (e == next_end) {
+            store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
+            set_infinity(acc);
+            do { b++; next_end = gstart[b + 1]; } while (next_end <= e); // skip empty buckets
+        }
+        const uint32_t v = sorted[e];
         uint32_t w[16];
         ld16(srs + (size_t)(v & 0x7fffffffu) * 16, w);
         AffineV<1> p;
         load_affine_m261(p, w);
         madd(acc, cond_neg_affine(p, (v >> 31) != 0));
     }
+    store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
+}
+
+// K4m: bucket b = sum of its partials, slots b + floor(s/ch) .. b + floor((e-1)/ch); written canonical for K5.
+// Buckets cut into more than MERGE_LIGHT partials (skewed digit distributions, the short top window) are queued and
+// summed by a whole workgroup each (K4h), so no lane ever walks a long list.
+constexpr uint32_t MERGE_LIGHT = 6;
+__global__ void __launch_bounds__(MSM_THREADS) msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+                                                              uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
+                                                              uint32_t ch)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= total_buckets) return;
+    const uint32_t s = gstart[b], e = gstart[b + 1];
+    Xyzz acc;
+    set_infinity(acc);
+    if (e > s) {
+        const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
+        if (t1 - t0 >= MERGE_LIGHT) { // heavy[0] = count, heavy[1..] = bucket ids
+            heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
+            return;
+        }
+        load_raw(acc, partials + (size_t)(b + t0) * RAW_WORDS);
+        for (uint32_t t = t0 + 1; t <= t1; t++) {
+            Xyzz q, r;
+            load_raw(q, partials + (size_t)(b + t) * RAW_WORDS);
+            add(r, acc, q);
+            acc = r;
+        }
+    }
     uint32_t o[32];
     store_xyzz(o, acc);
-    st32(buckets + (size_t)t * 32, o);
+    st32(buckets + (size_t)b * 32, o);
+}
+// K4h: one workgroup per queued bucket: strided in-lane sums, then an LDS tree
+__global__ void __launch_bounds__(MSM_THREADS) msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+                                                                    uint32_t* __restrict__ buckets, const uint32_t* __restrict__ heavy, uint32_t ch)
+{
+    __shared__ uint32_t sh[MSM_THREADS * RAW_WORDS];
+    const uint32_t count = heavy[0];
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        const uint32_t b = heavy[1 + item];
+        const uint32_t s = gstart[b], e = gstart[b + 1];
+        const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
+        Xyzz acc;
+        set_infinity(acc);
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += MSM_THREADS) {
+            Xyzz q, r;
+            load_raw(q, partials + (size_t)(b + t) * RAW_WORDS);
+            add(r, acc, q);
+            acc = r;
+        }
+        __syncthreads(); // previous item's readers are done with sh
+        store_raw(sh + threadIdx.x * RAW_WORDS, acc);
+        __syncthreads();
+        for (uint32_t half = MSM_THREADS / 2; half >= 1; half >>= 1) {
+            if (threadIdx.x < half) {
+                Xyzz p, q, r;
+                load_raw(p, sh + threadIdx.x * RAW_WORDS);
+                load_raw(q, sh + (threadIdx.x + half) * RAW_WORDS);
+                add(r, p, q);
+                store_raw(sh + threadIdx.x * RAW_WORDS, r);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            Xyzz r;
+            load_raw(r, sh);
+            uint32_t o[32];
+            store_xyzz(o, r);
+            st32(buckets + (size_t)b * 32, o);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -442,6 +578,19 @@ int msm_num_windows(int c)
 struct MsmPlan {
     uint32_t n, c, W, nb, hbits, lbits, slices, slice_len;
 };
+// chunk length of K4 for nw windows: aim at >= 4 waves per SIMD (2^18 lanes) with at least 16 entries per lane
+static uint32_t chunk_len(size_t n, uint32_t nw)
+{
+    const uint64_t m = (uint64_t)n * nw;
+    uint32_t ch = 64;
+    while (ch > 16 && m / ch < (1u << 18)) ch >>= 1;
+    return ch;
+}
+static size_t arena_points(const MsmPlan& P, uint32_t nw)
+{
+    const size_t H = (size_t)1 << P.hbits, L = (size_t)1 << P.lbits;
+    return (size_t)nw * (2 * P.nb + 2 * (P.hbits * H + P.lbits * L + 2 * H + 2 * L) + 64) + 4096;
+}
 static MsmPlan make_plan(size_t n, int c)
 {
     MsmPlan P;
@@ -465,10 +614,14 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     tot += al((size_t)P.W * n * 2);                          // digits
     tot += al((size_t)nw * P.slices * P.nb * 4);             // hist / cursors
-    tot += al((size_t)nw * (P.nb + 1) * 4);                  // bstart
+    tot += al(((size_t)nw * P.nb + 1) * 4);                  // gstart
+    tot += al((size_t)nw * 8 + 256);                         // totals, bases
+    tot += al(((size_t)nw * P.nb + 1) * 4);                  // heavy-bucket queue
     tot += al((size_t)nw * n * 4);                           // sorted
+    const size_t chunks = ((size_t)n * nw + 15) / 16 + 1;    // upper bound for any chunk length >= 16
+    tot += al(((size_t)nw * P.nb + chunks) * RAW_WORDS * 4); // partials
     tot += al((size_t)nw * P.nb * 128);                      // buckets
-    tot += al(((size_t)nw * P.nb * 2 + 4096) * 128);         // fold arena: rows < nb, cols < nb, slices/Z small
+    tot += al(arena_points(P, (uint32_t)nw) * 128);          // fold arena
     tot += al((size_t)nw * 64 * 128);                        // exported T points
     return tot;
 }
@@ -511,10 +664,15 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     uint8_t* p = ws.base;
     int16_t* digits = (int16_t*)p; p += al((size_t)P.W * n * 2);
     uint32_t* hist = (uint32_t*)p; p += al((size_t)nw * P.slices * P.nb * 4);
-    uint32_t* bstart = (uint32_t*)p; p += al((size_t)nw * (P.nb + 1) * 4);
+    uint32_t* gstart = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
+    uint32_t* totals = (uint32_t*)p; uint32_t* bases = totals + nw; p += al((size_t)nw * 8 + 256);
+    uint32_t* heavy = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
     uint32_t* sorted = (uint32_t*)p; p += al((size_t)nw * n * 4);
+    const size_t chunks_cap = ((size_t)n * nw + 15) / 16 + 1;
+    uint32_t* partials = (uint32_t*)p; p += al(((size_t)nw * P.nb + chunks_cap) * RAW_WORDS * 4);
     uint32_t* buckets = (uint32_t*)p; p += al((size_t)nw * P.nb * 128);
-    uint32_t* scratch = (uint32_t*)p; p += al(((size_t)nw * P.nb * 2 + 4096) * 128);
+    uint32_t* scratch = (uint32_t*)p; p += al(arena_points(P, nw) * 128);
+    uint32_t* scratch_end = (uint32_t*)p;
     uint32_t* texp = (uint32_t*)p;
 
     hipEvent_t ev[8];
@@ -535,12 +693,19 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
         attr = true;
     }
     msm_hist_kernel<<<dim3(P.slices, nw), SORT_THREADS, P.nb * 4, st>>>(digits, hist, P.n, P.nb, P.slices, P.slice_len, (uint32_t)wb);
-    msm_scan_kernel<<<nw, SORT_THREADS, 0, st>>>(hist, bstart, P.nb, P.slices);
-    msm_scatter_kernel<<<dim3(P.slices, nw), SORT_THREADS, P.nb * 4, st>>>(digits, hist, sorted, P.n, P.nb, P.slices, P.slice_len, (uint32_t)wb);
+    msm_colscan_kernel<<<(nw * P.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(hist, gstart, P.nb, P.slices, nw * P.nb);
+    msm_scan_kernel<<<nw, SORT_THREADS, 0, st>>>(gstart, totals, P.nb);
+    msm_bases_kernel<<<nw, SORT_THREADS, 0, st>>>(gstart, totals, bases, P.nb, nw);
+    msm_scatter_kernel<<<dim3(P.slices, nw), SORT_THREADS, P.nb * 4, st>>>(digits, hist, gstart, bases, sorted, P.n, P.nb, P.slices, P.slice_len, (uint32_t)wb);
     if (tm) HIPCHK(hipEventRecord(ev[2], st));
-    // K4
+    // K4 + K4m
     const uint32_t total_buckets = nw * P.nb;
-    msm_accumulate_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(d_srs, sorted, bstart, buckets, P.n, P.nb, total_buckets);
+    const uint32_t ch = chunk_len(n, nw);
+    const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
+    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(d_srs, sorted, gstart, partials, total_buckets, ch);
+    HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
+    msm_merge_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch);
+    msm_merge_heavy_kernel<<<1024, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
     if (tm) HIPCHK(hipEventRecord(ev[3], st));
 
     // K5: bucket b = hi * 2^l + lo carries weight b + 1:
@@ -548,7 +713,13 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     //   sum_hi hi * R_hi = sum_k 2^k TR_k, TR_k = sum of the R_hi whose bit k is set (same for C).
     const uint32_t H = 1u << P.hbits, L = 1u << P.lbits;
     uint32_t* bump = scratch;
-    auto alloc_pts = [&](size_t count) { uint32_t* r = bump; bump += count * 32; return r; };
+    bool arena_overflow = false;
+    auto alloc_pts = [&](size_t count) {
+        uint32_t* r = bump;
+        bump += count * 32;
+        if (bump > scratch_end) { arena_overflow = true; bump = scratch; r = scratch; } // never write past the arena
+        return r;
+    };
     struct Chain { const uint32_t* in; uint32_t groups, len, stop, gstride; };
     auto run_chains = [&](Chain* ch, int nch) -> int {
         for (;;) {
@@ -587,6 +758,11 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
                     { trbuf, nw * P.hbits, std::max(1u, H / 4), 1, std::max(1u, H / 4) },
                     { tcbuf, nw * std::max(1u, P.lbits), std::max(1u, L / 4), 1, std::max(1u, L / 4) } };
     run_chains(zt, 3);
+    if (arena_overflow) {
+        (void)hipStreamSynchronize(st);
+        set_error("internal: fold arena too small (n=%zu c=%u nw=%u)", n, P.c, nw);
+        return BBGPU_ERR_STATE;
+    }
     msm_collect_kernel<<<(nw * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, nw, P.hbits, P.lbits);
     if (tm) HIPCHK(hipEventRecord(ev[5], st));
     HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)nw * 64 * 128, hipMemcpyDeviceToHost, st));
