@@ -18,7 +18,7 @@ void ntt_release_tables();
 namespace host { struct Xyzz; }
 struct MsmTiming {
     int count = 0;
-    float ms[8]; // [0] total device time, then digits, sort, accumulate, rows/cols folds, slices+collect
+    float ms[8]; // [0] total device time, then digits, sort, accumulate kernel, merge, row/col folds, slices+collect
 };
 struct MsmWorkspace {
     uint8_t* base = nullptr;

@@ -703,10 +703,11 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     const uint32_t ch = chunk_len(n, nw);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
     msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(d_srs, sorted, gstart, partials, total_buckets, ch);
+    if (tm) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
     msm_merge_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch);
     msm_merge_heavy_kernel<<<1024, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
-    if (tm) HIPCHK(hipEventRecord(ev[3], st));
+    if (tm) HIPCHK(hipEventRecord(ev[4], st));
 
     // K5: bucket b = hi * 2^l + lo carries weight b + 1:
     //   S_w = Z + sum_lo lo * C_lo + 2^l * sum_hi hi * R_hi,   R = row sums (over lo), C = column sums (over hi), Z = sum R
@@ -744,7 +745,7 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     run_chains(rowcol, 2);
     const uint32_t* R = rowcol[0].in;  // [nw][H]
     const uint32_t* Cc = rowcol[1].in; // [nw][L]
-    if (tm) HIPCHK(hipEventRecord(ev[4], st));
+    if (tm) HIPCHK(hipEventRecord(ev[5], st));
     uint32_t* trbuf = alloc_pts((size_t)nw * P.hbits * std::max(1u, H / 4));
     uint32_t* tcbuf = alloc_pts((size_t)nw * std::max(1u, P.lbits) * std::max(1u, L / 4));
     {
@@ -764,7 +765,7 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
         return BBGPU_ERR_STATE;
     }
     msm_collect_kernel<<<(nw * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, nw, P.hbits, P.lbits);
-    if (tm) HIPCHK(hipEventRecord(ev[5], st));
+    if (tm) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)nw * 64 * 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
@@ -792,9 +793,9 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     if (tm) {
         float ms;
         timing->count = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
+        HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[6]));
         timing->ms[timing->count++] = ms;
-        for (int i = 0; i < 5; i++) {
+        for (int i = 0; i < 6; i++) {
             HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             timing->ms[timing->count++] = ms;
         }

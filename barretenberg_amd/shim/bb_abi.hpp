@@ -1,0 +1,90 @@
+// bb_abi.hpp -- the minimum of barretenberg's type system needed to DEFINE the reference's own symbols
+// (Itanium mangling and x86-64 SysV layout) from outside its source tree.  Declarations only: names, template
+// parameters, member order and alignments are an ABI necessity; no function bodies of the reference
+// appear here.  Sources of the layouts: fields/field.hpp:19-22 (field_t, alignas(32)), groups/group.hpp:17-28
+// (affine_element, element), polynomials/evaluation_domain.hpp:9-59 (member order),
+// curves/bn254/scalar_multiplication.hpp:88-94 (multiplication_state).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace barretenberg {
+
+template <typename FieldParams> class field {
+  public:
+    struct field_t {
+        alignas(32) uint64_t data[4];
+    };
+};
+class FrParams;
+class Bn254FqParams;
+struct Bn254G1Params;
+typedef field<Bn254FqParams> fq;
+typedef field<FrParams> fr;
+
+template <typename coordinate_field, typename subgroup_field, typename GroupParams> class group {
+  public:
+    struct affine_element {
+        typename coordinate_field::field_t x;
+        typename coordinate_field::field_t y;
+    };
+    struct element {
+        typename coordinate_field::field_t x;
+        typename coordinate_field::field_t y;
+        typename coordinate_field::field_t z;
+    };
+};
+typedef group<fq, fr, Bn254G1Params> g1;
+
+class evaluation_domain {
+  public:
+    size_t size;
+    size_t num_threads;
+    size_t thread_size;
+    size_t log2_size;
+    size_t log2_thread_size;
+    size_t log2_num_threads;
+    fr::field_t root;
+    fr::field_t root_inverse;
+    fr::field_t domain;
+    fr::field_t domain_inverse;
+    fr::field_t generator;
+    fr::field_t generator_inverse;
+
+  private:
+    std::vector<fr::field_t*> round_roots;
+    std::vector<fr::field_t*> inverse_round_roots;
+    fr::field_t* roots;
+};
+
+namespace scalar_multiplication {
+struct multiplication_state {
+    g1::affine_element* points;
+    fr::field_t* scalars;
+    size_t num_elements;
+    g1::element output;
+};
+g1::element pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width);
+void batched_scalar_multiplications(multiplication_state* mul_state, size_t num_batches);
+} // namespace scalar_multiplication
+
+namespace polynomial_arithmetic {
+void fft(fr::field_t* coeffs, const evaluation_domain& domain);
+void ifft(fr::field_t* coeffs, const evaluation_domain& domain);
+void coset_fft(fr::field_t* coeffs, const evaluation_domain& domain);
+void coset_ifft(fr::field_t* coeffs, const evaluation_domain& domain);
+void fft_with_constant(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& value);
+void ifft_with_constant(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& value);
+void coset_fft_with_constant(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& constant);
+} // namespace polynomial_arithmetic
+
+// layout probes (measured against the reference headers with sizeof/offsetof)
+static_assert(sizeof(fr::field_t) == 32 && alignof(fr::field_t) == 32, "field_t");
+static_assert(sizeof(g1::affine_element) == 64 && sizeof(g1::element) == 96, "g1 elements");
+static_assert(sizeof(scalar_multiplication::multiplication_state) == 128, "multiplication_state");
+static_assert(offsetof(scalar_multiplication::multiplication_state, output) == 32, "multiplication_state.output");
+static_assert(sizeof(evaluation_domain) == 320, "evaluation_domain");
+static_assert(offsetof(evaluation_domain, root) == 64 && offsetof(evaluation_domain, generator_inverse) == 224, "evaluation_domain fields");
+
+} // namespace barretenberg

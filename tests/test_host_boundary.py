@@ -93,3 +93,26 @@ def test_host_field_code_matches_oracle():
     subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, src, "-L" + ob, "-loracle", "-Wl,-rpath," + ob], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:]
+
+
+REFERENCE_SYMBOLS = [  # SURVEY 8b, taken from `nm` on the built reference objects
+    "_ZN12barretenberg21scalar_multiplication9pippengerEPNS_5fieldINS_8FrParamsEE7field_tEPNS_5groupINS1_INS_13Bn254FqParamsEEES3_NS_13Bn254G1ParamsEE14affine_elementEmm",
+    "_ZN12barretenberg21scalar_multiplication30batched_scalar_multiplicationsEPNS0_20multiplication_stateEm",
+    "_ZN12barretenberg21polynomial_arithmetic3fftEPNS_5fieldINS_8FrParamsEE7field_tERKNS_17evaluation_domainE",
+    "_ZN12barretenberg21polynomial_arithmetic4ifftEPNS_5fieldINS_8FrParamsEE7field_tERKNS_17evaluation_domainE",
+    "_ZN12barretenberg21polynomial_arithmetic9coset_fftEPNS_5fieldINS_8FrParamsEE7field_tERKNS_17evaluation_domainE",
+    "_ZN12barretenberg21polynomial_arithmetic10coset_ifftEPNS_5fieldINS_8FrParamsEE7field_tERKNS_17evaluation_domainE",
+    "_ZN12barretenberg21polynomial_arithmetic17fft_with_constantEPNS_5fieldINS_8FrParamsEE7field_tERKNS_17evaluation_domainERKS4_",
+    "_ZN12barretenberg21polynomial_arithmetic18ifft_with_constantEPNS_5fieldINS_8FrParamsEE7field_tERKNS_17evaluation_domainERKS4_",
+    "_ZN12barretenberg21polynomial_arithmetic23coset_fft_with_constantEPNS_5fieldINS_8FrParamsEE7field_tERKNS_17evaluation_domainERKS4_",
+]
+
+
+def test_shim_defines_reference_symbols(lib):
+    """the C++ shim exports exactly the mangled hot-path symbols of the reference (link-time drop-in)"""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "barretenberg_amd", "shim")], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "barretenberg_amd", "libbbshim.so")],
+                         capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"}
+    assert set(REFERENCE_SYMBOLS) <= defined
