@@ -34,7 +34,8 @@ NTT_KINDS = {
 C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
     "bbgpu_ntt_device", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_msm_g1",
-    "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_g1_sum", "bbgpu_last_timing",
+    "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_wait",
+    "bbgpu_g1_sum", "bbgpu_last_timing",
     "bbgpu_set_timing",
 ]
 
@@ -83,6 +84,8 @@ class BbGpu:
         L.bbgpu_msm_g1_batch.argtypes = [C.POINTER(MsmJob), C.c_size_t]
         L.bbgpu_msm_num_windows.argtypes = [C.c_size_t]
         L.bbgpu_msm_g1_device.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
+        L.bbgpu_msm_g1_device_async.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.bbgpu_msm_g1_wait.argtypes = [C.c_int, u64p]
         L.bbgpu_g1_sum.argtypes = [u64p, C.c_size_t, u64p]
         L.bbgpu_last_timing.argtypes = [C.POINTER(C.c_float), C.c_int]
         self.device = device
@@ -161,6 +164,18 @@ class BbGpu:
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.lib.bbgpu_msm_g1_device(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,
                                                _ptr(out), C.c_void_p(stream or 0)))
+        return out
+
+    def msm_device_async(self, handle, d_scalars_ptr, n, offset=0, window_begin=0, window_end=None, stream=None):
+        """enqueue; returns a ticket for msm_wait().  At most two MSMs in flight."""
+        if window_end is None:
+            window_end = self.msm_num_windows(n)
+        return self._chk(self.lib.bbgpu_msm_g1_device_async(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,
+                                                           C.c_void_p(stream or 0)))
+
+    def msm_wait(self, ticket):
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.lib.bbgpu_msm_g1_wait(ticket, _ptr(out)))
         return out
 
     def g1_sum(self, points12):

@@ -28,10 +28,20 @@ struct MsmWorkspace {
     int ensure(size_t bytes);
     void release();
 };
+struct MsmSlot {
+    MsmWorkspace ws;
+    hipStream_t stream = nullptr; // the slot's own stream (used when the caller passes none)
+    hipEvent_t done = nullptr;
+    hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    bool pending = false, trivial = false, timed = false;
+    size_t n = 0;
+    uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0;
+    void release();
+};
 int msm_choose_c(size_t n);
 int msm_num_windows(int c);
-int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, host::Xyzz* result,
-            hipStream_t st, MsmTiming* timing);
+int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st, bool want_timing);
+int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st);
 int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);
 

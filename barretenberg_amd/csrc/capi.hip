@@ -37,7 +37,8 @@ struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<SrsEntry> srs;
-    MsmWorkspace ws;
+    MsmSlot slot[2];
+    int next_slot = 0;
     uint64_t* d_stage = nullptr; // scalars / coefficients staging
     size_t stage_cap = 0;
     uint64_t* d_scratch = nullptr; // NTT scratch
@@ -134,7 +135,13 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
     CHK(hipMemcpyAsync(g_ctx.d_stage, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
     host::Xyzz res;
     const int W = msm_num_windows(msm_choose_c(n));
-    rc = msm_run(g_ctx.ws, g_ctx.srs[idx].d_srs + off * 16, g_ctx.d_stage, n, 0, W, &res, g_ctx.stream, g_ctx.timing ? &g_ctx.last : nullptr);
+    if (g_ctx.slot[0].pending) {
+        set_error("an asynchronous MSM is still in flight on slot 0: wait for it first");
+        return BBGPU_ERR_STATE;
+    }
+    rc = msm_issue(g_ctx.slot[0], g_ctx.srs[idx].d_srs + off * 16, g_ctx.d_stage, n, 0, W, g_ctx.stream, g_ctx.timing);
+    if (rc) return rc;
+    rc = msm_finish(g_ctx.slot[0], &res, &g_ctx.last);
     if (rc) return rc;
     host::g1_to_normalised(res, out);
     return BBGPU_OK;
@@ -178,7 +185,8 @@ void bbgpu_shutdown(void)
     for (auto& e : g_ctx.srs)
         if (e.live && e.d_srs) (void)hipFree(e.d_srs);
     g_ctx.srs.clear();
-    g_ctx.ws.release();
+    g_ctx.slot[0].release();
+    g_ctx.slot[1].release();
     if (g_ctx.d_stage) (void)hipFree(g_ctx.d_stage);
     if (g_ctx.d_scratch) (void)hipFree(g_ctx.d_scratch);
     g_ctx.d_stage = g_ctx.d_scratch = nullptr;
@@ -321,6 +329,14 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
 int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin, int window_end,
                         uint64_t out[12], void* hip_stream)
 {
+    int ticket = bbgpu_msm_g1_device_async(srs_handle, offset, d_scalars, n, window_begin, window_end, hip_stream);
+    if (ticket < 0) return ticket;
+    return bbgpu_msm_g1_wait(ticket, out);
+}
+
+int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin, int window_end,
+                              void* hip_stream)
+{
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     int rc = ensure_init();
     if (rc) return rc;
@@ -333,10 +349,31 @@ int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars
         set_error("MSM range [%zu, %zu) outside the registered table of %zu points", offset, offset + n, e.n);
         return BBGPU_ERR_ARG;
     }
-    host::Xyzz res;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
-    rc = msm_run(g_ctx.ws, e.d_srs + offset * 16, d_scalars, n, window_begin, window_end, &res, st, g_ctx.timing ? &g_ctx.last : nullptr);
+    int t = g_ctx.next_slot;
+    if (g_ctx.slot[t].pending) t ^= 1;
+    if (g_ctx.slot[t].pending) {
+        set_error("both MSM slots are in flight: call bbgpu_msm_g1_wait first");
+        return BBGPU_ERR_STATE;
+    }
+    MsmSlot& S = g_ctx.slot[t];
+    if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
+    rc = msm_issue(S, e.d_srs + offset * 16, d_scalars, n, window_begin, window_end, st, g_ctx.timing);
     if (rc == BBGPU_ERR_ARG) set_error("bad window range [%d, %d)", window_begin, window_end);
+    if (rc) return rc;
+    g_ctx.next_slot = t ^ 1;
+    return t;
+}
+
+int bbgpu_msm_g1_wait(int ticket, uint64_t out[12])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (ticket < 0 || ticket > 1 || !g_ctx.slot[ticket].pending) {
+        set_error("no MSM in flight for ticket %d", ticket);
+        return BBGPU_ERR_ARG;
+    }
+    host::Xyzz res;
+    int rc = msm_finish(g_ctx.slot[ticket], &res, &g_ctx.last);
     if (rc) return rc;
     host::g1_to_normalised(res, out);
     return BBGPU_OK;

@@ -155,67 +155,97 @@ template <class F, int L, int V> BB_HD Fe<F, 1, V> carry_full(const Fe<F, L, V>&
 }
 
 // ---- Montgomery multiplication, R = 2^261 -----------------------------------------------------------------------
-// columns: each <= 9*(L1*U)*(L2*U) + 9*2^58 + carry < 2^64 whenever L1*L2 <= 6.
-template <class F> BB_HD void mont_reduce_cols(uint64_t (&col)[2 * NL], uint32_t (&out)[NL])
+// every column sum is <= 9*(L1*U)*(L2*U) + 9*2^58 + carry < 2^64 whenever L1*L2 <= 6.
+// Fused product scanning: one 64-bit accumulator walks the 18 columns; the carry out of column k is the addend of the
+// first multiply-add of column k+1, so there is no column array and no 64-bit carry addition.
+template <class F> BB_HD void mul_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], uint32_t (&out)[NL])
 {
     uint32_t m[NL];
-    uint64_t carry = 0;
+    uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        uint64_t acc = col[k] + carry;
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a[i] * b[k - i];
 #pragma unroll
         for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::P[k - i];
         m[k] = ((uint32_t)acc * F::PINV) & M29;
         acc += (uint64_t)m[k] * F::P[0];
-        carry = acc >> 29;
+        acc >>= 29;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; k++) {
-        uint64_t acc = col[k] + carry;
+#pragma unroll
+        for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)a[i] * b[k - i];
 #pragma unroll
         for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)m[i] * F::P[k - i];
         out[k - NL] = (uint32_t)acc & M29;
-        carry = acc >> 29;
+        acc >>= 29;
     }
-    out[NL - 1] = (uint32_t)(col[2 * NL - 1] + carry);
-}
-
-template <class F> BB_HD void mul_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], uint32_t (&out)[NL])
-{
-    uint64_t col[2 * NL];
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) {
-        uint64_t acc = 0;
-#pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int j = k - i;
-            if (j >= 0 && j < NL) acc += (uint64_t)a[i] * b[j];
-        }
-        col[k] = acc;
-    }
-    col[2 * NL - 1] = 0;
-    mont_reduce_cols<F>(col, out);
+    out[NL - 1] = (uint32_t)acc;
 }
 
 template <class F> BB_HD void sqr_raw(const uint32_t (&a)[NL], uint32_t (&out)[NL])
 {
-    uint32_t a2[NL];
+    uint32_t a2[NL], m[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a[i] << 1;
-    uint64_t col[2 * NL];
+    uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
-        uint64_t acc = 0;
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int j = k - i;
             if (j > i && j < NL) acc += (uint64_t)a2[i] * a[j];
         }
         if ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
-        col[k] = acc;
+        if (k < NL) {
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::P[k - i];
+            m[k] = ((uint32_t)acc * F::PINV) & M29;
+            acc += (uint64_t)m[k] * F::P[0];
+        } else {
+#pragma unroll
+            for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)m[i] * F::P[k - i];
+            out[k - NL] = (uint32_t)acc & M29;
+        }
+        acc >>= 29;
     }
-    col[2 * NL - 1] = 0;
-    mont_reduce_cols<F>(col, out);
+    out[NL - 1] = (uint32_t)acc;
+}
+
+// a*b + c*d with ONE Montgomery reduction (81 multiply-adds saved): columns hold 18 + 18 products, so the limb bounds
+// must satisfy L1*L2 + L3*L4 <= 6.
+template <class F>
+BB_HD void mul2_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&c)[NL], const uint32_t (&d)[NL], uint32_t (&out)[NL])
+{
+    uint32_t m[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)a[i] * b[k - i];
+            acc += (uint64_t)c[i] * d[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::P[k - i];
+        m[k] = ((uint32_t)acc * F::PINV) & M29;
+        acc += (uint64_t)m[k] * F::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - (NL - 1); i < NL; i++) {
+            acc += (uint64_t)a[i] * b[k - i];
+            acc += (uint64_t)c[i] * d[k - i];
+        }
+#pragma unroll
+        for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)m[i] * F::P[k - i];
+        out[k - NL] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    out[NL - 1] = (uint32_t)acc;
 }
 
 constexpr int mul_v(int v1, int v2)
@@ -242,6 +272,27 @@ BB_HD Fe<F, 1, mul_v(V1, V2)> mul(const Fe<F, L1, V1>& a, const Fe<F, L2, V2>& b
         mul_raw<F>(an.d, bn.d, r.d);
     }
     return r;
+}
+
+constexpr int mul2_v(int v1, int v2, int v3, int v4)
+{
+    return (v1 * v2 + v3 * v4) / 169 + 2;
+}
+// a*b + c*d, one reduction
+template <class F, int L1, int V1, int L2, int V2, int L3, int V3, int L4, int V4>
+BB_HD Fe<F, 1, mul2_v(V1, V2, V3, V4)> mul_add(const Fe<F, L1, V1>& a, const Fe<F, L2, V2>& b, const Fe<F, L3, V3>& c, const Fe<F, L4, V4>& d)
+{
+    static_assert(L1 * L2 + L3 * L4 <= 6, "limb bounds too large for a shared reduction: weak() an operand");
+    static_assert(mul2_v(V1, V2, V3, V4) <= MAXV, "value bound too large");
+    Fe<F, 1, mul2_v(V1, V2, V3, V4)> r;
+    mul2_raw<F>(a.d, b.d, c.d, d.d, r.d);
+    return r;
+}
+// a*b - c*d = a*b + (Kp - c)*d, one reduction
+template <class F, int L1, int V1, int L2, int V2, int L3, int V3, int L4, int V4>
+BB_HD auto mul_sub(const Fe<F, L1, V1>& a, const Fe<F, L2, V2>& b, const Fe<F, L3, V3>& c, const Fe<F, L4, V4>& d)
+{
+    return mul_add(a, b, weak(neg(c)), d);
 }
 
 template <class F, int L1, int V1> BB_HD Fe<F, 1, mul_v(V1, V1)> sqr(const Fe<F, L1, V1>& a)

@@ -54,7 +54,7 @@ template <int V> BB_HD void dbl_affine(Xyzz& r, const AffineV<V>& a)
     auto XX = sqr(a.x);
     auto M = weak(add(dbl(XX), XX));               // 3*X^2 (a = 0)
     auto X3 = weak(sub(sqr(M), dbl(S)));           // M^2 - 2S
-    auto Y3 = weak(sub(mul(M, sub(S, X3)), mul(W, a.y)));
+    auto Y3 = mul_sub(M, sub(S, X3), W, a.y);
     r.x = X3;
     r.y = Y3;
     r.zz = Vv;
@@ -75,7 +75,7 @@ BB_HD void dbl(Xyzz& r, const Xyzz& p)
     auto XX = sqr(p.x);
     auto M = weak(add(dbl(XX), XX));
     auto X3 = weak(sub(sqr(M), dbl(S)));
-    auto Y3 = weak(sub(mul(M, sub(S, X3)), mul(W, p.y)));
+    auto Y3 = mul_sub(M, sub(S, X3), W, p.y);
     auto ZZ3 = mul(Vv, p.zz);
     auto ZZZ3 = mul(W, p.zzz);
     r.x = X3;
@@ -107,7 +107,7 @@ template <int V> BB_HD void madd(Xyzz& acc, const AffineV<V>& a)
     auto PPP = mul(P, PP);
     auto Q = mul(acc.x, PP);
     auto X3 = weak(sub(sqr(R), add(PPP, dbl(Q))));
-    auto Y3 = weak(sub(mul(R, sub(Q, X3)), mul(acc.y, PPP)));
+    auto Y3 = mul_sub(R, sub(Q, X3), acc.y, PPP);
     auto ZZ3 = mul(acc.zz, PP);
     auto ZZZ3 = mul(acc.zzz, PPP);
     acc.x = X3;
@@ -146,7 +146,7 @@ BB_HD void add(Xyzz& r, const Xyzz& p, const Xyzz& q)
     auto PPP = mul(P, PP);
     auto Q = mul(U1, PP);
     auto X3 = weak(sub(sqr(R), add(PPP, dbl(Q))));
-    auto Y3 = weak(sub(mul(R, sub(Q, X3)), mul(S1, PPP)));
+    auto Y3 = mul_sub(R, sub(Q, X3), S1, PPP);
     auto ZZ3 = mul(mul(p.zz, q.zz), PP);
     auto ZZZ3 = mul(mul(p.zzz, q.zzz), PPP);
     r.x = X3;

@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_merge_kernel(const uint32_t* 
                                                               uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
                                                               uint32_t ch)
 {
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total_buckets) return;
     const uint32_t s = gstart[b], e = gstart[b + 1];
@@ -418,6 +419,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_merge_kernel(const uint32_t* 
 __global__ void __launch_bounds__(MSM_THREADS) msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                                     uint32_t* __restrict__ buckets, const uint32_t* __restrict__ heavy, uint32_t ch)
 {
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[MSM_THREADS * RAW_WORDS];
     const uint32_t count = heavy[0];
     for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
@@ -472,6 +474,7 @@ struct FoldArgs {
 };
 __global__ void __launch_bounds__(MSM_THREADS) msm_fold_kernel(FoldArgs A)
 {
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     const FoldJob& J = A.job[blockIdx.y];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= J.groups * J.half) return;
@@ -504,6 +507,7 @@ __device__ __forceinline__ uint32_t insert_one_bit(uint32_t m, uint32_t k)
 }
 __global__ void __launch_bounds__(MSM_THREADS) msm_slice_kernel(SliceArgs A)
 {
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     const SliceJob& J = A.job[blockIdx.y];
     const uint32_t quarter = J.len >= 4 ? (J.len >> 2) : 1;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -530,6 +534,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_slice_kernel(SliceArgs A)
 __global__ void msm_collect_kernel(const uint32_t* __restrict__ z, const uint32_t* __restrict__ tr, const uint32_t* __restrict__ tc,
                                    uint32_t* __restrict__ out, uint32_t nw, uint32_t hbits, uint32_t lbits)
 {
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nw * 64) return;
     const uint32_t w = t >> 6, slot = t & 63;
@@ -578,13 +583,29 @@ int msm_num_windows(int c)
 struct MsmPlan {
     uint32_t n, c, W, nb, hbits, lbits, slices, slice_len;
 };
-// chunk length of K4 for nw windows: aim at >= 4 waves per SIMD (2^18 lanes) with at least 16 entries per lane
+// K4 residency: 3 workgroups of 256 lanes per CU (3 waves per SIMD; v_mad_u64_u32 issue saturates at 2).  The 4th slot is
+// deliberately left free -- enforced by a dynamic-LDS reservation -- so that the short latency-bound kernels of the
+// previous MSM's tail (merge, folds) can run beside the accumulation of the next one (two-slot pipeline).
+constexpr uint32_t ACC_WG_PER_CU = 3;
+constexpr uint32_t ACC_LDS_RESERVE = 41 * 1024; // 3 x 41 KiB fit in 160 KiB, 4 do not
+static uint32_t acc_capacity_lanes()
+{
+    static uint32_t lanes = 0;
+    if (!lanes) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        lanes = (uint32_t)cus * ACC_WG_PER_CU * MSM_THREADS;
+    }
+    return lanes;
+}
+// chunk length of K4: one resident wave of workgroups covers the whole entry list (no tail wave), >= 16 entries per lane
 static uint32_t chunk_len(size_t n, uint32_t nw)
 {
     const uint64_t m = (uint64_t)n * nw;
-    uint32_t ch = 64;
-    while (ch > 16 && m / ch < (1u << 18)) ch >>= 1;
-    return ch;
+    const uint32_t cap = acc_capacity_lanes();
+    uint32_t ch = (uint32_t)((m + cap - 1) / cap);
+    return ch < 16 ? 16 : ch;
 }
 static size_t arena_points(const MsmPlan& P, uint32_t nw)
 {
@@ -647,18 +668,26 @@ void MsmWorkspace::release()
 
 // Runs windows [wb, we) of the MSM of d_scalars[0..n) against resident points srs[0..n); returns the partial sum
 // sum_{w in [wb,we)} 2^(c w) S_w as host XYZZ (Montgomery 2^256).
-int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, host::Xyzz* result,
-            hipStream_t st, MsmTiming* timing)
+// Enqueues windows [wb, we) of the MSM of d_scalars[0..n) against resident points srs[0..n) on `st` (all kernels and the
+// final 16 KiB device-to-host copy of the per-window leftover points); returns without waiting.  msm_finish() waits for
+// the slot's event and runs the host tail.  Two slots let the tail of one MSM overlap the head of the next.
+int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st, bool want_timing)
 {
-    *result = host::g1_infinity();
-    if (n == 0) return BBGPU_OK;
+    MsmWorkspace& ws = S.ws;
+    S.n = n;
+    S.pending = false;
+    S.timed = false;
+    if (n == 0) { S.trivial = true; S.pending = true; return BBGPU_OK; }
+    S.trivial = false;
     const int c = msm_choose_c(n);
     const MsmPlan P = make_plan(n, c);
     if (wb < 0 || we > (int)P.W || wb >= we) return BBGPU_ERR_ARG;
     const uint32_t nw = (uint32_t)(we - wb);
+    S.c = P.c; S.nw = nw; S.wb = (uint32_t)wb; S.hbits = P.hbits; S.lbits = P.lbits;
     int rc = ws.ensure(MsmWorkspace::bytes_needed(n, c, (int)nw));
     if (rc) return rc;
     if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, 64 * 64 * 128));
+    if (!S.done) HIPCHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     uint8_t* p = ws.base;
@@ -675,11 +704,13 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     uint32_t* scratch_end = (uint32_t*)p;
     uint32_t* texp = (uint32_t*)p;
 
-    hipEvent_t ev[8];
-    const bool tm = timing != nullptr;
+    hipEvent_t* ev = S.ev;
+    const bool tm = want_timing;
     if (tm) {
-        for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+        if (!S.ev[0])
+            for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&S.ev[i]));
         HIPCHK(hipEventRecord(ev[0], st));
+        S.timed = true;
     }
 
     // K0
@@ -702,7 +733,7 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     const uint32_t total_buckets = nw * P.nb;
     const uint32_t ch = chunk_len(n, nw);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
-    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(d_srs, sorted, gstart, partials, total_buckets, ch);
+    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, ACC_LDS_RESERVE, st>>>(d_srs, sorted, gstart, partials, total_buckets, ch);
     if (tm) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
     msm_merge_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch);
@@ -767,41 +798,65 @@ int msm_run(MsmWorkspace& ws, const uint32_t* d_srs, const uint64_t* d_scalars, 
     msm_collect_kernel<<<(nw * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, nw, P.hbits, P.lbits);
     if (tm) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)nw * 64 * 128, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventRecord(S.done, st));
     HIPCHK(hipGetLastError());
+    S.pending = true;
+    return BBGPU_OK;
+}
 
-    // ---- host tail: S_w = Z + sum_k 2^k TC_k + 2^l sum_k 2^k TR_k ; result = sum_w 2^(c w) S_w (Horner from the top) --
+// Waits for an issued MSM and finishes it on the host:
+//   S_w = Z + sum_k 2^k TC_k + 2^l sum_k 2^k TR_k ;  result = sum_w 2^(c (wb + w)) S_w   (Horner from the top)
+int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing)
+{
+    *result = host::g1_infinity();
+    if (!S.pending) return BBGPU_ERR_STATE;
+    S.pending = false;
+    if (S.trivial) return BBGPU_OK;
+    HIPCHK(hipEventSynchronize(S.done));
+    const uint32_t nw = S.nw;
     auto pt = [&](uint32_t w, uint32_t slot) {
         host::Xyzz q;
-        memcpy(&q, (const uint8_t*)ws.h_out + ((size_t)w * 64 + slot) * 128, 128);
+        memcpy(&q, (const uint8_t*)S.ws.h_out + ((size_t)w * 64 + slot) * 128, 128);
         return q;
     };
     host::Xyzz acc = host::g1_infinity();
     for (int w = (int)nw - 1; w >= 0; --w) {
         host::Xyzz rs = host::g1_infinity();
-        for (int k = (int)P.hbits - 1; k >= 0; --k) rs = host::g1_add(host::g1_dbl(rs), pt(w, 1 + k));
-        for (uint32_t k = 0; k < P.lbits; k++) rs = host::g1_dbl(rs);
+        for (int k = (int)S.hbits - 1; k >= 0; --k) rs = host::g1_add(host::g1_dbl(rs), pt(w, 1 + k));
+        for (uint32_t k = 0; k < S.lbits; k++) rs = host::g1_dbl(rs);
         host::Xyzz cs = host::g1_infinity();
-        for (int k = (int)P.lbits - 1; k >= 0; --k) cs = host::g1_add(host::g1_dbl(cs), pt(w, 32 + k));
+        for (int k = (int)S.lbits - 1; k >= 0; --k) cs = host::g1_add(host::g1_dbl(cs), pt(w, 32 + k));
         host::Xyzz sw = host::g1_add(host::g1_add(rs, cs), pt(w, 0));
-        for (uint32_t k = 0; k < P.c; k++) acc = host::g1_dbl(acc);
+        for (uint32_t k = 0; k < S.c; k++) acc = host::g1_dbl(acc);
         acc = host::g1_add(acc, sw);
     }
-    for (uint32_t k = 0; k < P.c * (uint32_t)wb; k++) acc = host::g1_dbl(acc);
+    for (uint32_t k = 0; k < S.c * S.wb; k++) acc = host::g1_dbl(acc);
     *result = acc;
-
-    if (tm) {
+    if (S.timed && timing) {
         float ms;
         timing->count = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[6]));
+        HIPCHK(hipEventElapsedTime(&ms, S.ev[0], S.ev[6]));
         timing->ms[timing->count++] = ms;
         for (int i = 0; i < 6; i++) {
-            HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, S.ev[i], S.ev[i + 1]));
             timing->ms[timing->count++] = ms;
         }
-        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return BBGPU_OK;
+}
+
+void MsmSlot::release()
+{
+    ws.release();
+    if (done) (void)hipEventDestroy(done);
+    done = nullptr;
+    for (auto& e : ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+    pending = false;
 }
 
 // ---- SRS management --------------------------------------------------------------------------------------------------

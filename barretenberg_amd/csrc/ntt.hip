@@ -116,10 +116,64 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
     }
     __syncthreads();
 
-    // ---- log_s radix-2 DIT stages in LDS ---------------------------------------------------------------------------
-    const uint32_t half = S >> 1, nbf = cols * half;
-    for (uint32_t s = 0; s < A.log_s; s++) {
-        const uint32_t m = 1u << s;
+    // ---- log_s radix-2 DIT stages in LDS, two stages per LDS round trip (radix-2^2 groups of 4 elements) -------------
+    // Stage pair (s, s+1), m = 2^s: the group {e0, e0+m, e0+2m, e0+3m} is closed under both stages:
+    //   stage s   : (e0,e1) and (e2,e3) with w_{2m}^j         stage s+1 : (e0,e2) with w_{4m}^j, (e1,e3) with w_{4m}^(j+m)
+    // Intermediate sums stay lazy (no renormalisation between the two stages); same multiplies as radix-2, half the LDS
+    // traffic and half the barriers.
+    const uint32_t half = S >> 1;
+    uint32_t s = 0;
+    for (; s + 1 < A.log_s; s += 2) {
+        const uint32_t m = 1u << s, quarter = S >> 2, ngr = cols * quarter;
+        for (uint32_t gq = tid; gq < ngr; gq += NTT_THREADS) {
+            const uint32_t c = gq >> (A.log_s - 2), q = gq & (quarter - 1);
+            const uint32_t j = q & (m - 1);
+            const uint32_t e0 = c * S + (((q >> s) << (s + 2)) | j);
+            FrL x0, x1, x2, x3;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                x0.d[l] = lds[l * E + e0];
+                x1.d[l] = lds[l * E + e0 + m];
+                x2.d[l] = lds[l * E + e0 + 2 * m];
+                x3.d[l] = lds[l * E + e0 + 3 * m];
+            }
+            // stage s
+            Fe<Fr, 2, NTT_VMAX + 3> a0, a2;
+            Fe<Fr, 4, NTT_VMAX + 4> a1, a3;
+            if (s == 0) { // twiddle one
+                // value bound: inputs come straight from unpack()/pre-scale (< 6p), so x +- y stays far below NTT_VMAX
+                a0 = assume_bound<2, NTT_VMAX + 3>(add(x0, x1));
+                a1 = assume_bound<4, NTT_VMAX + 4>(sub(x0, x1));
+                a2 = assume_bound<2, NTT_VMAX + 3>(add(x2, x3));
+                a3 = assume_bound<4, NTT_VMAX + 4>(sub(x2, x3));
+            } else {
+                const FeT<Fr> w1 = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
+                const auto t1 = mul(w1, x1), t3 = mul(w1, x3); // < 3p
+                a0 = add(x0, t1);
+                a1 = sub(x0, t1);
+                a2 = add(x2, t3);
+                a3 = sub(x2, t3);
+            }
+            // stage s+1
+            const FeT<Fr> w2a = load_tw(A.tw_sub, j << (A.log_s - 2 - s));
+            const FeT<Fr> w2b = load_tw(A.tw_sub, (j + m) << (A.log_s - 2 - s));
+            const auto u2 = mul(w2a, a2), u3 = mul(w2b, a3); // < 3p
+            const FrL y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, u2)));
+            const FrL y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, u2)));
+            const FrL y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
+            const FrL y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                lds[l * E + e0] = y0.d[l];
+                lds[l * E + e0 + m] = y1.d[l];
+                lds[l * E + e0 + 2 * m] = y2.d[l];
+                lds[l * E + e0 + 3 * m] = y3.d[l];
+            }
+        }
+        __syncthreads();
+    }
+    if (s < A.log_s) { // odd number of stages: one plain radix-2 stage left
+        const uint32_t m = 1u << s, nbf = cols * half;
         for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
             const uint32_t c = bf >> (A.log_s - 1), i = bf & (half - 1);
             const uint32_t j = i & (m - 1);
@@ -130,23 +184,20 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
                 x.d[l] = lds[l * E + lo];
                 y.d[l] = lds[l * E + hi];
             }
-            if (s == 0) { // twiddle is one: x' = x + y, y' = x - y
-                FrL xs = assume_bound<1, NTT_VMAX>(weak(add(x, y)));
-                FrL ys = assume_bound<1, NTT_VMAX>(weak(sub(x, y)));
-                x = xs;
-                y = ys;
+            FrL xs, ys;
+            if (s == 0) {
+                xs = assume_bound<1, NTT_VMAX>(weak(add(x, y)));
+                ys = assume_bound<1, NTT_VMAX>(weak(sub(x, y)));
             } else {
-                FeT<Fr> w = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
-                auto t = mul(w, y); // < 3p
-                FrL xs = assume_bound<1, NTT_VMAX>(weak(add(x, t)));
-                FrL ys = assume_bound<1, NTT_VMAX>(weak(sub(x, t)));
-                x = xs;
-                y = ys;
+                const FeT<Fr> w = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
+                const auto t = mul(w, y);
+                xs = assume_bound<1, NTT_VMAX>(weak(add(x, t)));
+                ys = assume_bound<1, NTT_VMAX>(weak(sub(x, t)));
             }
 #pragma unroll
             for (int l = 0; l < NL; l++) {
-                lds[l * E + lo] = x.d[l];
-                lds[l * E + hi] = y.d[l];
+                lds[l * E + lo] = xs.d[l];
+                lds[l * E + hi] = ys.d[l];
             }
         }
         __syncthreads();

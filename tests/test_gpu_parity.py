@@ -231,6 +231,37 @@ def test_msm_window_sharding_adds_up(gpu, oracle, msm_small):
         assert np.array_equal(gpu.g1_sum(np.stack(partials)), full), parts
 
 
+def test_msm_async_pipeline(gpu, oracle, msm_small):
+    """two MSMs in flight (bbgpu_msm_g1_device_async / _wait): results independent of the overlap"""
+    import torch
+    from barretenberg_amd import BbGpuError
+    g, srs, table, scalars = msm_small
+    h = gpu.srs_register(table)
+    sizes = [4096, 1000, 65536, 16, 10000]
+    d = {n: torch.from_numpy(scalars[:n].view(np.int64)).cuda() for n in sizes}
+    want = {n: [c for c in g["cases"] if c["n"] == n and "x" in c][0] for n in sizes}
+    inflight, got = [], []
+    for n in sizes + sizes:
+        inflight.append((n, gpu.msm_device_async(h, d[n].data_ptr(), n)))
+        if len(inflight) == 2:
+            m, t = inflight.pop(0)
+            got.append((m, gpu.msm_wait(t)))
+    with pytest.raises(BbGpuError):
+        gpu.msm_device_async(h, d[16].data_ptr(), 16) and gpu.msm_device_async(h, d[16].data_ptr(), 16)
+    while inflight:
+        m, t = inflight.pop(0)
+        got.append((m, gpu.msm_wait(t)))
+    # drain whatever the failed double-issue left behind
+    for t in (0, 1):
+        try:
+            gpu.msm_wait(t)
+        except BbGpuError:
+            pass
+    assert len(got) == 10
+    for m, out in got:
+        _check(out, want[m])
+
+
 def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
     """BASELINE config 2: 2^20-point MSM, random scalars vs the synthetic SRS; expected point from the reference."""
     import torch
