@@ -41,6 +41,8 @@ struct Context {
     int next_slot = 0;
     uint64_t* d_stage = nullptr; // scalars / coefficients staging
     size_t stage_cap = 0;
+    uint64_t* d_stage2 = nullptr; // second scalar staging buffer (pipelined batches)
+    size_t stage2_cap = 0;
     uint64_t* d_scratch = nullptr; // NTT scratch
     size_t scratch_cap = 0;
     bool timing = false;
@@ -188,6 +190,9 @@ void bbgpu_shutdown(void)
     g_ctx.slot[0].release();
     g_ctx.slot[1].release();
     if (g_ctx.d_stage) (void)hipFree(g_ctx.d_stage);
+    if (g_ctx.d_stage2) (void)hipFree(g_ctx.d_stage2);
+    g_ctx.d_stage2 = nullptr;
+    g_ctx.stage2_cap = 0;
     if (g_ctx.d_scratch) (void)hipFree(g_ctx.d_scratch);
     g_ctx.d_stage = g_ctx.d_scratch = nullptr;
     g_ctx.stage_cap = g_ctx.scratch_cap = 0;
@@ -319,11 +324,53 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
             return BBGPU_ERR_ARG;
         }
     }
-    for (size_t i = 0; i < num_jobs; i++) {
-        rc = msm_host_ptrs(jobs[i].scalars, jobs[i].points, jobs[i].num_elements, jobs[i].output);
-        if (rc) return rc;
+    const size_t n = jobs[0].num_elements;
+    if (n == 0 || g_ctx.slot[0].pending || g_ctx.slot[1].pending) {
+        for (size_t i = 0; i < num_jobs; i++) {
+            rc = msm_host_ptrs(jobs[i].scalars, jobs[i].points, jobs[i].num_elements, jobs[i].output);
+            if (rc) return rc;
+        }
+        return BBGPU_OK;
     }
-    return BBGPU_OK;
+    // Two-slot pipeline over the jobs of a prover round (3/1/3/2 MSMs, prover.cpp:65-122,650-658): job i+1's scalars
+    // cross PCIe and its kernels are enqueued while job i's bucket-reduction tail and host finish run.
+    uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
+    size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
+    const int W = msm_num_windows(msm_choose_c(n));
+    auto issue = [&](size_t i) -> int {
+        const int t = (int)(i & 1);
+        MsmSlot& S = g_ctx.slot[t];
+        if (!jobs[i].scalars || !jobs[i].points) {
+            set_error("null scalars/points in job %zu", i);
+            return BBGPU_ERR_ARG;
+        }
+        size_t off = 0;
+        int idx = find_srs(jobs[i].points, n, &off);
+        if (idx < 0) {
+            uint32_t* d = nullptr;
+            int r = srs_upload(jobs[i].points, n, &d, g_ctx.stream);
+            if (r) return r;
+            g_ctx.srs.push_back({ jobs[i].points, n, d, true });
+            idx = (int)g_ctx.srs.size() - 1;
+        }
+        int r = grow(stage[t], cap[t], n * 32);
+        if (r) return r;
+        if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        CHK(hipMemcpyAsync(*stage[t], jobs[i].scalars, n * 32, hipMemcpyHostToDevice, S.stream));
+        return msm_issue(S, g_ctx.srs[idx].d_srs + off * 16, *stage[t], n, 0, W, S.stream, false);
+    };
+    auto finish = [&](size_t i) -> int {
+        host::Xyzz res;
+        int r = msm_finish(g_ctx.slot[i & 1], &res, nullptr);
+        if (r) return r;
+        host::g1_to_normalised(res, jobs[i].output);
+        return BBGPU_OK;
+    };
+    for (size_t i = 0; i < num_jobs; i++) {
+        if ((rc = issue(i)) != BBGPU_OK) return rc;
+        if (i >= 1 && (rc = finish(i - 1)) != BBGPU_OK) return rc;
+    }
+    return finish(num_jobs - 1);
 }
 
 int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin, int window_end,

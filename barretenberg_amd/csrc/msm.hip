@@ -25,6 +25,7 @@
 #include <mutex>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -216,104 +217,127 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(const uint32_t*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// K1/K3: per (slice, window) counting sort, histogram / cursors in LDS
+// K1-K3: two-pass counting sort of (window, bucket) -> point index, every pass coalesced.
+//   bucket = bin * 2^LB + lo.  Pass A bins entries by (window, bin) -- 2^HB <= 256 bins, histogram and cursors in LDS --
+//   so that one workgroup's output per bin is a contiguous run; pass B gives every (window, bin) to one workgroup which
+//   counting-sorts its few thousand entries by `lo` inside a 16 KiB neighbourhood that stays in L2.
+//   (A single-pass scatter of 4-byte entries into the 64 MiB list was measured at 8x write amplification: PMC
+//   WRITE_SIZE 525 MB for 64 MiB of payload, 0.22 ms.)
+//   tmp entry: point index (24 bits) | lo << 24 (7 bits) | sign << 31.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 1024;
-__global__ void __launch_bounds__(SORT_THREADS) msm_hist_kernel(const int16_t* __restrict__ digits, uint32_t* __restrict__ hist, uint32_t n,
-                                                              uint32_t nb, uint32_t slices, uint32_t slice_len, uint32_t win0)
+constexpr uint32_t SORT_MAX_LB = 7;
+
+__global__ void __launch_bounds__(SORT_THREADS) sortA_hist_kernel(const int16_t* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
+                                                                uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0)
 {
-    extern __shared__ uint32_t lh[];
+    __shared__ uint32_t lh[256];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) lh[b] = 0;
+    if (threadIdx.x < 256) lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
     const int16_t* dg = digits + (size_t)(win0 + wl) * n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         const int d = dg[i];
-        if (d) atomicAdd(&lh[(d < 0 ? -d : d) - 1], 1u);
+        if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
     }
     __syncthreads();
-    uint32_t* out = hist + ((size_t)wl * slices + s) * nb;
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) out[b] = lh[b];
+    if (threadIdx.x < bins) histA[((size_t)wl * slices + s) * bins + threadIdx.x] = lh[threadIdx.x];
 }
 
-// K2a: for every (window, bucket) column: exclusive prefix over slices in place (cursors relative to the bucket start)
-// and the bucket's total.  One lane per bucket -> coalesced across lanes, nw * nb lanes.
-__global__ void __launch_bounds__(MSM_THREADS) msm_colscan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ gstart, uint32_t nb,
-                                                                uint32_t slices, uint32_t total_buckets)
+// per window (one block of 256 threads = bins): cursors relative to the bin start (exclusive over slices), local bin
+// starts (exclusive over bins) and the window's entry count
+__global__ void __launch_bounds__(256) sortA_scan_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ binstart, uint32_t* __restrict__ totals,
+                                                        uint32_t bins, uint32_t slices)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_buckets) return;
-    const uint32_t wl = t / nb, b = t - wl * nb;
-    uint32_t* H = hist + (size_t)wl * slices * nb + b;
-    uint32_t run = 0;
-    for (uint32_t s = 0; s < slices; s++) {
-        const uint32_t cnt = H[(size_t)s * nb];
-        H[(size_t)s * nb] = run;
-        run += cnt;
-    }
-    gstart[t] = run; // bucket size for now
-}
-// K2b: per window: exclusive scan of the bucket sizes -> local bucket starts, and the window's entry count
-__global__ void __launch_bounds__(SORT_THREADS) msm_scan_kernel(uint32_t* __restrict__ gstart, uint32_t* __restrict__ totals, uint32_t nb)
-{
-    __shared__ uint32_t part[SORT_THREADS];
+    __shared__ uint32_t part[256];
     const uint32_t wl = blockIdx.x, t = threadIdx.x;
-    uint32_t* G = gstart + (size_t)wl * nb;
-    const uint32_t per = (nb + SORT_THREADS - 1) / SORT_THREADS;
-    const uint32_t b0 = min(nb, t * per), b1 = min(nb, b0 + per);
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++) sum += G[b];
-    part[t] = sum;
+    uint32_t run = 0;
+    if (t < bins) {
+        uint32_t* H = histA + (size_t)wl * slices * bins + t;
+        for (uint32_t s = 0; s < slices; s++) {
+            const uint32_t cnt = H[(size_t)s * bins];
+            H[(size_t)s * bins] = run;
+            run += cnt;
+        }
+    }
+    part[t] = run;
     __syncthreads();
-    for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) { // inclusive Hillis-Steele scan
+    for (uint32_t off = 1; off < 256; off <<= 1) {
         uint32_t v = t >= off ? part[t - off] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    uint32_t run = part[t] - sum;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t cnt = G[b];
-        G[b] = run;
-        run += cnt;
-    }
-    if (t == SORT_THREADS - 1) totals[wl] = part[SORT_THREADS - 1];
+    if (t < bins) binstart[(size_t)wl * bins + t] = part[t] - run;
+    if (t == 255) totals[wl] = part[255];
 }
-// K2c: make the bucket starts global (entries of all windows form one compact sorted list); bases[w] for the scatter
-__global__ void __launch_bounds__(SORT_THREADS) msm_bases_kernel(uint32_t* __restrict__ gstart, const uint32_t* __restrict__ totals,
-                                                               uint32_t* __restrict__ bases, uint32_t nb, uint32_t nw)
+// window bases (exclusive prefix of the window totals), M = total number of entries -> gstart[total_buckets]
+__global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t nw)
 {
-    const uint32_t wl = blockIdx.x;
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < wl; w++) base += totals[w];
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) gstart[(size_t)wl * nb + b] += base;
-    if (threadIdx.x == 0) {
-        bases[wl] = base;
-        if (wl == nw - 1) gstart[(size_t)nw * nb] = base + totals[wl]; // M = total number of entries
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < nw; w++) {
+            bases[w] = run;
+            run += totals[w];
+        }
+        bases[nw] = run;
+        *gstart_end = run;
     }
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) msm_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursors,
-                                                                 const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ bases,
-                                                                 uint32_t* __restrict__ sorted,
-                                                                 uint32_t n, uint32_t nb, uint32_t slices, uint32_t slice_len, uint32_t win0)
+__global__ void __launch_bounds__(SORT_THREADS) sortA_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursorsA,
+                                                                   const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
+                                                                   uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
+                                                                   uint32_t slices, uint32_t slice_len, uint32_t win0)
 {
-    extern __shared__ uint32_t lc[];
+    __shared__ uint32_t lc[256];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
-    const uint32_t* cur = cursors + ((size_t)wl * slices + s) * nb;
-    (void)bases;
-    const uint32_t* gs = gstart + (size_t)wl * nb; // already global (K2c)
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) lc[b] = cur[b] + gs[b];
+    if (threadIdx.x < bins)
+        lc[threadIdx.x] = cursorsA[((size_t)wl * slices + s) * bins + threadIdx.x] + binstart[(size_t)wl * bins + threadIdx.x] + bases[wl];
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
     const int16_t* dg = digits + (size_t)(win0 + wl) * n;
+    const uint32_t lomask = (1u << lb) - 1;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         const int d = dg[i];
         if (d) {
-            const uint32_t pos = atomicAdd(&lc[(d < 0 ? -d : d) - 1], 1u);
-            sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+            const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
+            const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
+            tmp[pos] = i | ((b & lomask) << 24) | (d < 0 ? 0x80000000u : 0u);
         }
+    }
+}
+
+// pass B: one workgroup per (bin, window): counting sort by `lo`, emits the final entries and the global bucket starts
+__global__ void __launch_bounds__(256) sortB_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binstart,
+                                                   const uint32_t* __restrict__ bases, uint32_t* __restrict__ sorted, uint32_t* __restrict__ gstart,
+                                                   uint32_t bins, uint32_t lb, uint32_t nb)
+{
+    __shared__ uint32_t cnt[128];
+    __shared__ uint32_t cur[128];
+    const uint32_t bin = blockIdx.x, wl = blockIdx.y, t = threadIdx.x;
+    const uint32_t nlo = 1u << lb;
+    const uint32_t start = bases[wl] + binstart[(size_t)wl * bins + bin];
+    const uint32_t end = (bin + 1 < bins) ? bases[wl] + binstart[(size_t)wl * bins + bin + 1] : bases[wl + 1];
+    if (t < 128) cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t e = start + t; e < end; e += 256) atomicAdd(&cnt[(tmp[e] >> 24) & 0x7f], 1u);
+    __syncthreads();
+    if (t == 0) { // 128 counters: a serial scan is cheaper than a barrier ladder
+        uint32_t run = start;
+        for (uint32_t k = 0; k < nlo; k++) {
+            cur[k] = run;
+            run += cnt[k];
+        }
+    }
+    __syncthreads();
+    if (t < nlo) gstart[(size_t)wl * nb + (size_t)bin * nlo + t] = cur[t];
+    __syncthreads();
+    for (uint32_t e = start + t; e < end; e += 256) {
+        const uint32_t v = tmp[e];
+        const uint32_t pos = atomicAdd(&cur[(v >> 24) & 0x7f], 1u);
+        sorted[pos] = v & 0x80ffffffu;
     }
 }
 
@@ -581,7 +605,7 @@ int msm_num_windows(int c)
 }
 
 struct MsmPlan {
-    uint32_t n, c, W, nb, hbits, lbits, slices, slice_len;
+    uint32_t n, c, W, nb, hbits, lbits, slices, slice_len, sort_lb, sort_bins;
 };
 // K4 residency: 3 workgroups of 256 lanes per CU (3 waves per SIMD; v_mad_u64_u32 issue saturates at 2).  The 4th slot is
 // deliberately left free -- enforced by a dynamic-LDS reservation -- so that the short latency-bound kernels of the
@@ -621,7 +645,9 @@ static MsmPlan make_plan(size_t n, int c)
     P.nb = 1u << (c - 1);
     P.lbits = (c - 1) / 2;
     P.hbits = (c - 1) - P.lbits;
-    P.slices = std::max<uint32_t>(1, 256 / P.W);
+    P.slices = std::max<uint32_t>(1, 512 / P.W);
+    P.sort_lb = std::min<uint32_t>(SORT_MAX_LB, (uint32_t)c - 1);
+    P.sort_bins = P.nb >> P.sort_lb; // <= 256 for c <= 16
     if ((uint64_t)P.slices * 4096 > n) P.slices = std::max<uint32_t>(1, (uint32_t)(n / 4096));
     P.slice_len = (uint32_t)((n + P.slices - 1) / P.slices);
     return P;
@@ -634,9 +660,11 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     size_t tot = 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     tot += al((size_t)P.W * n * 2);                          // digits
-    tot += al((size_t)nw * P.slices * P.nb * 4);             // hist / cursors
+    tot += al((size_t)nw * P.slices * P.sort_bins * 4);      // pass-A histogram / cursors
+    tot += al((size_t)nw * P.sort_bins * 4 + 256);           // bin starts
+    tot += al((size_t)nw * n * 4);                           // pass-A output
     tot += al(((size_t)nw * P.nb + 1) * 4);                  // gstart
-    tot += al((size_t)nw * 8 + 256);                         // totals, bases
+    tot += al((size_t)nw * 8 + 512);                         // totals, bases (nw + 1)
     tot += al(((size_t)nw * P.nb + 1) * 4);                  // heavy-bucket queue
     tot += al((size_t)nw * n * 4);                           // sorted
     const size_t chunks = ((size_t)n * nw + 15) / 16 + 1;    // upper bound for any chunk length >= 16
@@ -679,6 +707,10 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size
     S.timed = false;
     if (n == 0) { S.trivial = true; S.pending = true; return BBGPU_OK; }
     S.trivial = false;
+    if (n > ((size_t)1 << 24)) { // sort entries carry a 24-bit point index
+        set_error("MSM of %zu points: at most 2^24 points per call", n);
+        return BBGPU_ERR_SIZE;
+    }
     const int c = msm_choose_c(n);
     const MsmPlan P = make_plan(n, c);
     if (wb < 0 || we > (int)P.W || wb >= we) return BBGPU_ERR_ARG;
@@ -692,9 +724,11 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     uint8_t* p = ws.base;
     int16_t* digits = (int16_t*)p; p += al((size_t)P.W * n * 2);
-    uint32_t* hist = (uint32_t*)p; p += al((size_t)nw * P.slices * P.nb * 4);
+    uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * P.sort_bins * 4);
+    uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * P.sort_bins * 4 + 256);
+    uint32_t* tmp_entries = (uint32_t*)p; p += al((size_t)nw * n * 4);
     uint32_t* gstart = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
-    uint32_t* totals = (uint32_t*)p; uint32_t* bases = totals + nw; p += al((size_t)nw * 8 + 256);
+    uint32_t* totals = (uint32_t*)p; uint32_t* bases = totals + nw; p += al((size_t)nw * 8 + 512);
     uint32_t* heavy = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
     uint32_t* sorted = (uint32_t*)p; p += al((size_t)nw * n * 4);
     const size_t chunks_cap = ((size_t)n * nw + 15) / 16 + 1;
@@ -717,17 +751,12 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size
     msm_digits_kernel<<<(P.n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>((const uint32_t*)d_scalars, digits, P.n, P.c, P.W);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MSM_MAX_C - 1)) * 4));
-        HIPCHK(hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << (MSM_MAX_C - 1)) * 4));
-        attr = true;
-    }
-    msm_hist_kernel<<<dim3(P.slices, nw), SORT_THREADS, P.nb * 4, st>>>(digits, hist, P.n, P.nb, P.slices, P.slice_len, (uint32_t)wb);
-    msm_colscan_kernel<<<(nw * P.nb + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(hist, gstart, P.nb, P.slices, nw * P.nb);
-    msm_scan_kernel<<<nw, SORT_THREADS, 0, st>>>(gstart, totals, P.nb);
-    msm_bases_kernel<<<nw, SORT_THREADS, 0, st>>>(gstart, totals, bases, P.nb, nw);
-    msm_scatter_kernel<<<dim3(P.slices, nw), SORT_THREADS, P.nb * 4, st>>>(digits, hist, gstart, bases, sorted, P.n, P.nb, P.slices, P.slice_len, (uint32_t)wb);
+    sortA_hist_kernel<<<dim3(P.slices, nw), SORT_THREADS, 0, st>>>(digits, histA, P.n, P.sort_bins, P.sort_lb, P.slices, P.slice_len, (uint32_t)wb);
+    sortA_scan_kernel<<<nw, 256, 0, st>>>(histA, binstart, totals, P.sort_bins, P.slices);
+    sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)nw * P.nb, nw);
+    sortA_scatter_kernel<<<dim3(P.slices, nw), SORT_THREADS, 0, st>>>(digits, histA, binstart, bases, tmp_entries, P.n, P.sort_bins, P.sort_lb, P.slices,
+                                                                      P.slice_len, (uint32_t)wb);
+    sortB_kernel<<<dim3(P.sort_bins, nw), 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, P.sort_bins, P.sort_lb, P.nb);
     if (tm) HIPCHK(hipEventRecord(ev[2], st));
     // K4 + K4m
     const uint32_t total_buckets = nw * P.nb;
