@@ -93,20 +93,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=LOG2N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.same_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     G = BbGpu(device=local_rank)
     n = 1 << args.log2n
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -122,20 +130,26 @@ def main():
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
     W = G.msm_num_windows(n)
     wb, we = W * rank // world, W * (rank + 1) // world
-    gather_buf = [torch.empty(12, dtype=torch.int64, device=dev) for _ in range(world)] if world > 1 else None
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the 96-byte partial sums are exchanged
+    gather_buf = [torch.empty(12, dtype=torch.int64, device=xdev) for _ in range(world)] if world > 1 else None
 
     def issue():
         return G.msm_device_async(srs, d_scalars.data_ptr(), n, 0, wb, we) if we > wb else None
 
+    stage_log = []  # per-MSM stage times (HIP events on the stream the kernels ran on), filled while timing is on
+
     def finish(ticket):
         if ticket is not None:
             part = G.msm_wait(ticket)
+            tm = G.last_timing()
+            if len(tm) >= 7:
+                stage_log.append(tm[:7])
         else:
             part = np.zeros(12, dtype=np.uint64)
             part[7] = np.uint64(1 << 63)
         if world == 1:
             return part
-        mine = torch.from_numpy(part.view(np.int64)).to(dev)
+        mine = torch.from_numpy(part.view(np.int64)).to(xdev)
         dist.all_gather(gather_buf, mine)  # the path's one exchange step: 96 bytes per rank over xGMI
         allp = torch.stack(gather_buf).cpu().numpy().view(np.uint64)
         return G.g1_sum(allp)
@@ -153,13 +167,19 @@ def main():
         return res
 
     res = run_steps(args.warmup)
+    # live per-kernel timing INSIDE the timed region: the library brackets every stage with HIP events on the stream the
+    # kernels are launched on (two event records per stage; the kernels themselves are unchanged)
+    G.set_timing(True)
+    stage_log.clear()
     barrier()
     t0 = time.perf_counter()
     res = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    G.set_timing(False)
+    stage_pipe = np.mean(np.array(stage_log), axis=0) if stage_log else np.zeros(7)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     msm_ms = dt / args.steps * 1e3
@@ -170,7 +190,7 @@ def main():
     barrier()
     msm_latency_ms = (time.perf_counter() - t0) / 5 * 1e3
 
-    # ---- dominant kernel, timed live with HIP events on its own stream (library-internal events around each stage) ---
+    # ---- the same stages with nothing else on the GPU (one MSM at a time), for comparison ---------------------------
     G.set_timing(True)
     stage = np.zeros(7)
     reps = 5
@@ -208,7 +228,7 @@ def main():
 
     if rank == 0:
         alg_bytes = n * (32 + 64) + 96  # every scalar and base point once, one result
-        acc_ms = float(stage[3])
+        acc_ms = float(stage_pipe[3]) if stage_pipe[3] > 0 else float(stage[3])  # average over the timed region's launches
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -235,9 +255,14 @@ def main():
             "config": {"workload": "2^%d-point BN254 G1 MSM, uniformly random 253-bit scalars vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
                        "parallelism": "digit windows [%d) sharded over %d rank(s), one all-gather of 96 B partial sums" % (W, world) if world > 1 else "single GPU, %d windows of 16 bits" % W},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
-                         "merge": float(stage[4]), "bucket_folds": float(stage[5]), "slices_collect": float(stage[6])},
+                         "merge": float(stage[4]), "bucket_folds": float(stage[5]), "slices_collect": float(stage[6]),
+                         "note": "one MSM at a time (no overlap)"},
+            "stage_ms_in_timed_region": {"device_total": float(stage_pipe[0]), "digits": float(stage_pipe[1]), "sort": float(stage_pipe[2]),
+                                         "accumulate": float(stage_pipe[3]), "merge": float(stage_pipe[4]), "bucket_folds": float(stage_pipe[5]),
+                                         "slices_collect": float(stage_pipe[6]),
+                                         "note": "two MSMs in flight: stages of consecutive steps overlap, so they sum to more than ms_per_step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "msm_accumulate_kernel",
+                         "traffic": traffic, "kernel": "msm_accumulate_kernel", "kernel_ms": acc_ms, "kernel_ms_alone": float(stage[3]),
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes},
             "ntt": {"metric": "Fr radix-2 NTT elements/s at n=2^%d, in place on a device-resident vector" % args.log2n,
                     "fft": ntt["fft"], "coset_fft": ntt["coset_fft"],

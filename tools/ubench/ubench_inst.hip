@@ -47,6 +47,9 @@ __global__ void __launch_bounds__(256) NAME(uint64_t* out, uint32_t sa, uint32_t
 #define OP_AND(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
 #define OP_MADU32(i) asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
 #define OP_PKFMA32(i) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(a[i]));
+#define OP_LSHR64(i) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(a[i]));
+#define OP_LSHR32(i) asm volatile("v_lshrrev_b32 %0, 29, %0" : "+v"(a[i]));
+#define OP_MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(x));
 #define OP_DOT4(i) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
 
 KERNEL(k_mad64, DECL64, OP_MAD64, FOLD64)
@@ -66,6 +69,9 @@ KERNEL(k_and, DECL32, OP_AND, FOLD32)
 KERNEL(k_madu16, DECL32, OP_MADU32, FOLD32)
 KERNEL(k_pkfma32, DECL64, OP_PKFMA32, FOLD64)
 KERNEL(k_dot4, DECL32, OP_DOT4, FOLD32)
+KERNEL(k_lshr64, DECL64, OP_LSHR64, FOLD64)
+KERNEL(k_lshr32, DECL32, OP_LSHR32, FOLD32)
+KERNEL(k_mov, DECL32, OP_MOV, FOLD32)
 
 typedef void (*kern_t)(uint64_t*, uint32_t, uint32_t);
 struct Entry { const char* name; kern_t k; };
@@ -75,7 +81,7 @@ int main() {
                 {"v_add_co_u32", k_addco}, {"v_addc_co_u32", k_addc}, {"v_add3_u32", k_add3}, {"v_mad_u32_u24", k_mad24},
                 {"v_mul_hi_u32_u24", k_mulhi24}, {"v_lshl_add_u64", k_lshladd64}, {"v_fma_f64", k_fma64},
                 {"v_alignbit_b32", k_alignbit}, {"v_cndmask_b32", k_cndmask}, {"v_and_b32", k_and}, {"v_mad_u32_u16", k_madu16},
-                {"v_pk_fma_f32", k_pkfma32}, {"v_dot4_u32_u8", k_dot4}};
+                {"v_pk_fma_f32", k_pkfma32}, {"v_dot4_u32_u8", k_dot4}, {"v_lshrrev_b64", k_lshr64}, {"v_lshrrev_b32", k_lshr32}, {"v_mov_b32", k_mov}};
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   int cus = prop.multiProcessorCount;
   printf("device %s CUs %d clock %d kHz\n", prop.name, cus, prop.clockRate);
