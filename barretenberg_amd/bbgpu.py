@@ -33,7 +33,8 @@ NTT_KINDS = {
 
 C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
-    "bbgpu_ntt_device", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_msm_g1",
+    "bbgpu_ntt_device", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
+    "bbgpu_srs_num_windows", "bbgpu_msm_g1",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing",
     "bbgpu_set_timing",
@@ -83,6 +84,7 @@ class BbGpu:
         L.bbgpu_msm_g1.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1_batch.argtypes = [C.POINTER(MsmJob), C.c_size_t]
         L.bbgpu_msm_num_windows.argtypes = [C.c_size_t]
+        L.bbgpu_srs_num_windows.argtypes = [C.c_int, C.c_size_t]
         L.bbgpu_msm_g1_device.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
         L.bbgpu_msm_g1_device_async.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.bbgpu_msm_g1_wait.argtypes = [C.c_int, u64p]
@@ -158,9 +160,15 @@ class BbGpu:
     def msm_num_windows(self, n):
         return int(self.lib.bbgpu_msm_num_windows(n))
 
+    def srs_num_windows(self, handle, n):
+        return self._chk(self.lib.bbgpu_srs_num_windows(handle, n))
+
+    def set_precompute(self, on=True):
+        self.lib.bbgpu_set_precompute(1 if on else 0)
+
     def msm_device(self, handle, d_scalars_ptr, n, offset=0, window_begin=0, window_end=None, stream=None):
         if window_end is None:
-            window_end = self.msm_num_windows(n)
+            window_end = self.srs_num_windows(handle, n)
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.lib.bbgpu_msm_g1_device(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,
                                                _ptr(out), C.c_void_p(stream or 0)))
@@ -169,7 +177,7 @@ class BbGpu:
     def msm_device_async(self, handle, d_scalars_ptr, n, offset=0, window_begin=0, window_end=None, stream=None):
         """enqueue; returns a ticket for msm_wait().  At most two MSMs in flight."""
         if window_end is None:
-            window_end = self.msm_num_windows(n)
+            window_end = self.srs_num_windows(handle, n)
         return self._chk(self.lib.bbgpu_msm_g1_device_async(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,
                                                            C.c_void_p(stream or 0)))
 

@@ -40,7 +40,9 @@ struct MsmSlot {
 };
 int msm_choose_c(size_t n);
 int msm_num_windows(int c);
-int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st, bool want_timing);
+int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
+              int we, hipStream_t st, bool want_timing);
+int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uint32_t** d_tab_out, hipStream_t st);
 int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st);
 int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);

@@ -30,6 +30,8 @@ struct SrsEntry {
     size_t n;
     uint32_t* d_srs;
     bool live;
+    uint32_t* d_tab = nullptr; // pre-shifted window tables [tab_W][n], or null
+    int tab_c = 0, tab_W = 0;
 };
 
 struct Context {
@@ -46,6 +48,7 @@ struct Context {
     uint64_t* d_scratch = nullptr; // NTT scratch
     size_t scratch_cap = 0;
     bool timing = false;
+    bool precompute = true; // build window tables for registered SRS (bbgpu_set_precompute)
     MsmTiming last;
 };
 
@@ -84,6 +87,33 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
     CHK(hipMalloc((void**)buf, bytes));
     *cap = bytes;
     return BBGPU_OK;
+}
+
+// registers resident points; builds the pre-shifted window tables when enabled and the 24-bit row index allows it
+int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs)
+{
+    SrsEntry e;
+    e.host_ptr = host_ptr;
+    e.n = n;
+    e.d_srs = d_srs;
+    e.live = true;
+    const int c = msm_choose_c(n), W = msm_num_windows(c);
+    if (g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24)) {
+        int rc = srs_build_table(d_srs, n, c, W, &e.d_tab, g_ctx.stream);
+        if (rc) return rc;
+        e.tab_c = c;
+        e.tab_W = W;
+    }
+    g_ctx.srs.push_back(e);
+    return (int)g_ctx.srs.size() - 1;
+}
+int entry_windows(const SrsEntry& e, size_t n)
+{
+    return e.d_tab ? e.tab_W : msm_num_windows(msm_choose_c(n ? n : 1));
+}
+int issue_on_entry(MsmSlot& S, const SrsEntry& e, size_t off, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st)
+{
+    return msm_issue(S, e.d_srs + off * 16, e.d_tab ? e.d_tab + off * 16 : nullptr, e.n, e.tab_c, d_scalars, n, wb, we, st, g_ctx.timing);
 }
 
 // table lookup by host address: returns entry index and point offset, or -1
@@ -128,20 +158,20 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         uint32_t* d = nullptr;
         int rc = srs_upload(points, n, &d, g_ctx.stream);
         if (rc) return rc;
-        g_ctx.srs.push_back({ points, n, d, true });
-        idx = (int)g_ctx.srs.size() - 1;
+        idx = add_srs(points, n, d);
+        if (idx < 0) return idx;
         off = 0;
     }
     int rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
     if (rc) return rc;
     CHK(hipMemcpyAsync(g_ctx.d_stage, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
     host::Xyzz res;
-    const int W = msm_num_windows(msm_choose_c(n));
+    const int W = entry_windows(g_ctx.srs[idx], n);
     if (g_ctx.slot[0].pending) {
         set_error("an asynchronous MSM is still in flight on slot 0: wait for it first");
         return BBGPU_ERR_STATE;
     }
-    rc = msm_issue(g_ctx.slot[0], g_ctx.srs[idx].d_srs + off * 16, g_ctx.d_stage, n, 0, W, g_ctx.stream, g_ctx.timing);
+    rc = issue_on_entry(g_ctx.slot[0], g_ctx.srs[idx], off, g_ctx.d_stage, n, 0, W, g_ctx.stream);
     if (rc) return rc;
     rc = msm_finish(g_ctx.slot[0], &res, &g_ctx.last);
     if (rc) return rc;
@@ -184,8 +214,10 @@ void bbgpu_shutdown(void)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g_ctx.ready) return;
     (void)hipStreamSynchronize(g_ctx.stream);
-    for (auto& e : g_ctx.srs)
+    for (auto& e : g_ctx.srs) {
         if (e.live && e.d_srs) (void)hipFree(e.d_srs);
+        if (e.live && e.d_tab) (void)hipFree(e.d_tab);
+    }
     g_ctx.srs.clear();
     g_ctx.slot[0].release();
     g_ctx.slot[1].release();
@@ -268,8 +300,7 @@ int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n)
     uint32_t* d = nullptr;
     rc = srs_upload(points_endo_table, n, &d, g_ctx.stream);
     if (rc) return rc;
-    g_ctx.srs.push_back({ points_endo_table, n, d, true });
-    return (int)g_ctx.srs.size() - 1;
+    return add_srs(points_endo_table, n, d);
 }
 
 int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out)
@@ -281,8 +312,7 @@ int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_tab
     uint32_t* d = nullptr;
     rc = srs_generate(x_mont, n, &d, host_endo_table_out, g_ctx.stream);
     if (rc) return rc;
-    g_ctx.srs.push_back({ host_endo_table_out, n, d, true });
-    return (int)g_ctx.srs.size() - 1;
+    return add_srs(host_endo_table_out, n, d);
 }
 
 int bbgpu_srs_release(int handle)
@@ -291,8 +321,10 @@ int bbgpu_srs_release(int handle)
     if (handle < 0 || handle >= (int)g_ctx.srs.size() || !g_ctx.srs[handle].live) return BBGPU_ERR_ARG;
     (void)hipStreamSynchronize(g_ctx.stream);
     (void)hipFree(g_ctx.srs[handle].d_srs);
+    if (g_ctx.srs[handle].d_tab) (void)hipFree(g_ctx.srs[handle].d_tab);
     g_ctx.srs[handle].live = false;
     g_ctx.srs[handle].d_srs = nullptr;
+    g_ctx.srs[handle].d_tab = nullptr;
     return BBGPU_OK;
 }
 
@@ -300,6 +332,17 @@ int bbgpu_srs_release(int handle)
 int bbgpu_msm_num_windows(size_t n)
 {
     return msm_num_windows(msm_choose_c(n ? n : 1));
+}
+int bbgpu_srs_num_windows(int srs_handle, size_t n)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (srs_handle < 0 || srs_handle >= (int)g_ctx.srs.size() || !g_ctx.srs[srs_handle].live) return BBGPU_ERR_ARG;
+    return entry_windows(g_ctx.srs[srs_handle], n);
+}
+void bbgpu_set_precompute(int enabled)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    g_ctx.precompute = enabled != 0;
 }
 
 int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12])
@@ -336,7 +379,6 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
     // cross PCIe and its kernels are enqueued while job i's bucket-reduction tail and host finish run.
     uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
     size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
-    const int W = msm_num_windows(msm_choose_c(n));
     auto issue = [&](size_t i) -> int {
         const int t = (int)(i & 1);
         MsmSlot& S = g_ctx.slot[t];
@@ -350,14 +392,14 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
             uint32_t* d = nullptr;
             int r = srs_upload(jobs[i].points, n, &d, g_ctx.stream);
             if (r) return r;
-            g_ctx.srs.push_back({ jobs[i].points, n, d, true });
-            idx = (int)g_ctx.srs.size() - 1;
+            idx = add_srs(jobs[i].points, n, d);
+            if (idx < 0) return idx;
         }
         int r = grow(stage[t], cap[t], n * 32);
         if (r) return r;
         if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         CHK(hipMemcpyAsync(*stage[t], jobs[i].scalars, n * 32, hipMemcpyHostToDevice, S.stream));
-        return msm_issue(S, g_ctx.srs[idx].d_srs + off * 16, *stage[t], n, 0, W, S.stream, false);
+        return issue_on_entry(S, g_ctx.srs[idx], off, *stage[t], n, 0, entry_windows(g_ctx.srs[idx], n), S.stream);
     };
     auto finish = [&](size_t i) -> int {
         host::Xyzz res;
@@ -405,7 +447,7 @@ int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_s
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
-    rc = msm_issue(S, e.d_srs + offset * 16, d_scalars, n, window_begin, window_end, st, g_ctx.timing);
+    rc = issue_on_entry(S, e, offset, d_scalars, n, window_begin, window_end, st);
     if (rc == BBGPU_ERR_ARG) set_error("bad window range [%d, %d)", window_begin, window_end);
     if (rc) return rc;
     g_ctx.next_slot = t ^ 1;

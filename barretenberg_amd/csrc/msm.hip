@@ -112,6 +112,43 @@ __global__ void srs_export_kernel(const uint32_t* __restrict__ srs, uint32_t* __
     for (int k = 0; k < 8; k++) dst[24 + k] = o[k];
 }
 
+// ---- pre-shifted window tables: tab[w * n + i] = 2^(c w) * P_i, affine canonical Montgomery-261 -----------------------
+// (the reference's generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129, built on the device).
+// One lane per base point: c doublings per window, one inversion per stored point.  Once per SRS.
+__global__ void __launch_bounds__(MSM_THREADS) srs_table_kernel(const uint32_t* __restrict__ srs, uint32_t* __restrict__ tab, uint32_t n, uint32_t c,
+                                                              uint32_t num_windows)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w16[16];
+    ld16(srs + (size_t)i * 16, w16);
+    {
+        uint4* q = reinterpret_cast<uint4*>(tab + (size_t)i * 16);
+#pragma unroll
+        for (int t = 0; t < 4; t++) q[t] = make_uint4(w16[4 * t], w16[4 * t + 1], w16[4 * t + 2], w16[4 * t + 3]);
+    }
+    AffineV<1> p;
+    load_affine_m261(p, w16);
+    Xyzz acc;
+    from_affine(acc, p);
+    for (uint32_t w = 1; w < num_windows; w++) {
+        for (uint32_t k = 0; k < c; k++) {
+            Xyzz t;
+            dbl(t, acc);
+            acc = t;
+        }
+        // 2^(c w) P is never infinity: the group order is an odd prime
+        const uint64_t e[4] = { Fq::P64[0] - 2, Fq::P64[1], Fq::P64[2], Fq::P64[3] };
+        auto inv = pow_u256<Fq>(mul(acc.zz, acc.zzz), e);
+        auto izz = mul(inv, acc.zzz), izzz = mul(inv, acc.zz);
+        uint32_t o[16];
+        store_affine_m261(o, mul(acc.x, izz), mul(acc.y, izzz));
+        uint4* q = reinterpret_cast<uint4*>(tab + ((size_t)w * n + i) * 16);
+#pragma unroll
+        for (int t = 0; t < 4; t++) q[t] = make_uint4(o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]);
+    }
+}
+
 // ---- synthetic SRS x^i G (fixed-base, 8-bit windows) ----------------------------------------------------------------
 // tab[w][d] = d * 2^(8w) * G as XYZZ words, d in [0,256) (d = 0: infinity)
 __global__ void srs_gen_table_kernel(uint32_t* __restrict__ tab)
@@ -228,29 +265,34 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(const uint32_t*
 constexpr int SORT_THREADS = 1024;
 constexpr uint32_t SORT_MAX_LB = 7;
 
+// A "group" is a set of `wpg` consecutive windows that share one bucket set: 1 window per group normally, all windows of
+// the call in one group when the SRS carries pre-shifted window tables (the window weight is then baked into the point).
 __global__ void __launch_bounds__(SORT_THREADS) sortA_hist_kernel(const int16_t* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
-                                                                uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0)
+                                                                uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0,
+                                                                uint32_t wpg)
 {
-    __shared__ uint32_t lh[256];
+    __shared__ uint32_t lh[SORT_THREADS];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
-    if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+    lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
-    const int16_t* dg = digits + (size_t)(win0 + wl) * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        const int d = dg[i];
-        if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
+    for (uint32_t k = 0; k < wpg; k++) {
+        const int16_t* dg = digits + (size_t)(win0 + wl * wpg + k) * n;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+            const int d = dg[i];
+            if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < bins) histA[((size_t)wl * slices + s) * bins + threadIdx.x] = lh[threadIdx.x];
 }
 
-// per window (one block of 256 threads = bins): cursors relative to the bin start (exclusive over slices), local bin
+// per group (one block, one thread per bin, bins <= 1024): cursors relative to the bin start (exclusive over slices), local bin
 // starts (exclusive over bins) and the window's entry count
-__global__ void __launch_bounds__(256) sortA_scan_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ binstart, uint32_t* __restrict__ totals,
-                                                        uint32_t bins, uint32_t slices)
+__global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ binstart,
+                                                                uint32_t* __restrict__ totals, uint32_t bins, uint32_t slices)
 {
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t part[SORT_THREADS];
     const uint32_t wl = blockIdx.x, t = threadIdx.x;
     uint32_t run = 0;
     if (t < bins) {
@@ -263,14 +305,14 @@ __global__ void __launch_bounds__(256) sortA_scan_kernel(uint32_t* __restrict__ 
     }
     part[t] = run;
     __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
+    for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
         uint32_t v = t >= off ? part[t - off] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
     if (t < bins) binstart[(size_t)wl * bins + t] = part[t] - run;
-    if (t == 255) totals[wl] = part[255];
+    if (t == SORT_THREADS - 1) totals[wl] = part[SORT_THREADS - 1];
 }
 // window bases (exclusive prefix of the window totals), M = total number of entries -> gstart[total_buckets]
 __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t nw)
@@ -289,28 +331,33 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
 __global__ void __launch_bounds__(SORT_THREADS) sortA_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursorsA,
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                    uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
-                                                                   uint32_t slices, uint32_t slice_len, uint32_t win0)
+                                                                   uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
+                                                                   uint32_t idx_stride)
 {
-    __shared__ uint32_t lc[256];
+    __shared__ uint32_t lc[SORT_THREADS];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
     if (threadIdx.x < bins)
         lc[threadIdx.x] = cursorsA[((size_t)wl * slices + s) * bins + threadIdx.x] + binstart[(size_t)wl * bins + threadIdx.x] + bases[wl];
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
-    const int16_t* dg = digits + (size_t)(win0 + wl) * n;
     const uint32_t lomask = (1u << lb) - 1;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        const int d = dg[i];
-        if (d) {
-            const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
-            const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
-            tmp[pos] = i | ((b & lomask) << 24) | (d < 0 ? 0x80000000u : 0u);
+    for (uint32_t k = 0; k < wpg; k++) {
+        const uint32_t wabs = win0 + wl * wpg + k;
+        const int16_t* dg = digits + (size_t)wabs * n;
+        const uint32_t row = wabs * idx_stride; // row of the pre-shifted table (0 without tables)
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+            const int d = dg[i];
+            if (d) {
+                const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
+                const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
+                tmp[pos] = (row + i) | ((b & lomask) << 24) | (d < 0 ? 0x80000000u : 0u);
+            }
         }
     }
 }
 
 // pass B: one workgroup per (bin, window): counting sort by `lo`, emits the final entries and the global bucket starts
-__global__ void __launch_bounds__(256) sortB_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binstart,
+__global__ void __launch_bounds__(SORT_THREADS) sortB_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binstart,
                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ sorted, uint32_t* __restrict__ gstart,
                                                    uint32_t bins, uint32_t lb, uint32_t nb)
 {
@@ -322,7 +369,7 @@ __global__ void __launch_bounds__(256) sortB_kernel(const uint32_t* __restrict__
     const uint32_t end = (bin + 1 < bins) ? bases[wl] + binstart[(size_t)wl * bins + bin + 1] : bases[wl + 1];
     if (t < 128) cnt[t] = 0;
     __syncthreads();
-    for (uint32_t e = start + t; e < end; e += 256) atomicAdd(&cnt[(tmp[e] >> 24) & 0x7f], 1u);
+    for (uint32_t e = start + t; e < end; e += blockDim.x) atomicAdd(&cnt[(tmp[e] >> 24) & 0x7f], 1u);
     __syncthreads();
     if (t == 0) { // 128 counters: a serial scan is cheaper than a barrier ladder
         uint32_t run = start;
@@ -334,7 +381,7 @@ __global__ void __launch_bounds__(256) sortB_kernel(const uint32_t* __restrict__
     __syncthreads();
     if (t < nlo) gstart[(size_t)wl * nb + (size_t)bin * nlo + t] = cur[t];
     __syncthreads();
-    for (uint32_t e = start + t; e < end; e += 256) {
+    for (uint32_t e = start + t; e < end; e += blockDim.x) {
         const uint32_t v = tmp[e];
         const uint32_t pos = atomicAdd(&cur[(v >> 24) & 0x7f], 1u);
         sorted[pos] = v & 0x80ffffffu;
@@ -391,18 +438,26 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint3
     uint32_t next_end = gstart[b + 1];
     Xyzz acc;
     set_infinity(acc);
+    // software pipeline: the gather of entry e+1 (index, then 64 bytes of point, possibly from HBM when the window
+    // tables exceed the Infinity Cache) is in flight while the ~2,300 VALU instructions of the mixed addition of entry e run
+    uint32_t v = sorted[p0];
+    uint32_t w[16];
+    ld16(srs + (size_t)(v & 0x7fffffffu) * 16, w);
     for (uint32_t e = p0; e < p1; e++) {
+        const uint32_t vn = sorted[min(e + 1, p1 - 1)];
+        uint32_t wn[16];
+        ld16(srs + (size_t)(vn & 0x7fffffffu) * 16, wn);
         if (e == next_end) {
             store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
             set_infinity(acc);
             do { b++; next_end = gstart[b + 1]; } while (next_end <= e); // skip empty buckets
         }
-        const uint32_t v = sorted[e];
-        uint32_t w[16];
-        ld16(srs + (size_t)(v & 0x7fffffffu) * 16, w);
         AffineV<1> p;
         load_affine_m261(p, w);
         madd(acc, cond_neg_affine(p, (v >> 31) != 0));
+        v = vn;
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = wn[i];
     }
     store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
 }
@@ -410,10 +465,9 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint3
 // K4m: bucket b = sum of its partials, slots b + floor(s/ch) .. b + floor((e-1)/ch); written canonical for K5.
 // Buckets cut into more than MERGE_LIGHT partials (skewed digit distributions, the short top window) are queued and
 // summed by a whole workgroup each (K4h), so no lane ever walks a long list.
-constexpr uint32_t MERGE_LIGHT = 6;
 __global__ void __launch_bounds__(MSM_THREADS) msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                               uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
-                                                              uint32_t ch)
+                                                              uint32_t ch, uint32_t MERGE_LIGHT)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -660,8 +714,8 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     size_t tot = 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     tot += al((size_t)P.W * n * 2);                          // digits
-    tot += al((size_t)nw * P.slices * P.sort_bins * 4);      // pass-A histogram / cursors
-    tot += al((size_t)nw * P.sort_bins * 4 + 256);           // bin starts
+    tot += al((size_t)nw * P.slices * 1024 * 4);             // pass-A histogram / cursors (<= 1024 bins)
+    tot += al((size_t)nw * 1024 * 4 + 256);                  // bin starts
     tot += al((size_t)nw * n * 4);                           // pass-A output
     tot += al(((size_t)nw * P.nb + 1) * 4);                  // gstart
     tot += al((size_t)nw * 8 + 512);                         // totals, bases (nw + 1)
@@ -699,7 +753,11 @@ void MsmWorkspace::release()
 // Enqueues windows [wb, we) of the MSM of d_scalars[0..n) against resident points srs[0..n) on `st` (all kernels and the
 // final 16 KiB device-to-host copy of the per-window leftover points); returns without waiting.  msm_finish() waits for
 // the slot's event and runs the host tail.  Two slots let the tail of one MSM overlap the head of the next.
-int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st, bool want_timing)
+// Table mode (d_tab != nullptr): d_tab[w * tab_stride + i] = 2^(tab_c * w) * P_i for the points of this call, so every window
+// feeds ONE shared bucket set (groups = 1): the bucket reduction and the host finish shrink 16-fold and no positional
+// doublings are needed.
+int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
+              int we, hipStream_t st, bool want_timing)
 {
     MsmWorkspace& ws = S.ws;
     S.n = n;
@@ -711,11 +769,22 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size
         set_error("MSM of %zu points: at most 2^24 points per call", n);
         return BBGPU_ERR_SIZE;
     }
-    const int c = msm_choose_c(n);
+    const bool table = d_tab != nullptr;
+    const int c = table ? tab_c : msm_choose_c(n);
     const MsmPlan P = make_plan(n, c);
     if (wb < 0 || we > (int)P.W || wb >= we) return BBGPU_ERR_ARG;
-    const uint32_t nw = (uint32_t)(we - wb);
-    S.c = P.c; S.nw = nw; S.wb = (uint32_t)wb; S.hbits = P.hbits; S.lbits = P.lbits;
+    const uint32_t nw = (uint32_t)(we - wb);      // windows processed
+    const uint32_t G = table ? 1u : nw;           // bucket sets ("groups")
+    const uint32_t wpg = table ? nw : 1u;         // windows per group
+    // one shared bucket set holds nw times the entries: finer bins (<= 1024) keep pass B's per-workgroup share small
+    uint32_t sort_lb = P.sort_lb, sort_bins = P.sort_bins;
+    if (table)
+        while (sort_bins < 1024 && sort_lb > 3) { sort_lb--; sort_bins <<= 1; }
+    const uint32_t slices = table ? std::max<uint32_t>(1, P.slices * nw / 2) : P.slices;
+    const uint32_t slice_len = (uint32_t)((n + slices - 1) / slices);
+    const uint32_t idx_stride = table ? (uint32_t)tab_stride : 0u;
+    const uint32_t* points = table ? d_tab : d_srs;
+    S.c = P.c; S.nw = G; S.wb = table ? 0u : (uint32_t)wb; S.hbits = P.hbits; S.lbits = P.lbits;
     int rc = ws.ensure(MsmWorkspace::bytes_needed(n, c, (int)nw));
     if (rc) return rc;
     if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, 64 * 64 * 128));
@@ -724,8 +793,8 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     uint8_t* p = ws.base;
     int16_t* digits = (int16_t*)p; p += al((size_t)P.W * n * 2);
-    uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * P.sort_bins * 4);
-    uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * P.sort_bins * 4 + 256);
+    uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * 1024 * 4);
+    uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
     uint32_t* tmp_entries = (uint32_t*)p; p += al((size_t)nw * n * 4);
     uint32_t* gstart = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
     uint32_t* totals = (uint32_t*)p; uint32_t* bases = totals + nw; p += al((size_t)nw * 8 + 512);
@@ -751,21 +820,23 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size
     msm_digits_kernel<<<(P.n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>((const uint32_t*)d_scalars, digits, P.n, P.c, P.W);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
-    sortA_hist_kernel<<<dim3(P.slices, nw), SORT_THREADS, 0, st>>>(digits, histA, P.n, P.sort_bins, P.sort_lb, P.slices, P.slice_len, (uint32_t)wb);
-    sortA_scan_kernel<<<nw, 256, 0, st>>>(histA, binstart, totals, P.sort_bins, P.slices);
-    sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)nw * P.nb, nw);
-    sortA_scatter_kernel<<<dim3(P.slices, nw), SORT_THREADS, 0, st>>>(digits, histA, binstart, bases, tmp_entries, P.n, P.sort_bins, P.sort_lb, P.slices,
-                                                                      P.slice_len, (uint32_t)wb);
-    sortB_kernel<<<dim3(P.sort_bins, nw), 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, P.sort_bins, P.sort_lb, P.nb);
+    sortA_hist_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
+    sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(histA, binstart, totals, sort_bins, slices);
+    sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
+    sortA_scatter_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
+                                                                   slice_len, (uint32_t)wb, wpg, idx_stride);
+    sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     if (tm) HIPCHK(hipEventRecord(ev[2], st));
     // K4 + K4m
-    const uint32_t total_buckets = nw * P.nb;
+    const uint32_t total_buckets = G * P.nb;
     const uint32_t ch = chunk_len(n, nw);
+    // in-lane merge limit: with one shared bucket set every bucket is cut into ~ n*nw / (nb*ch) + 1 partials
+    const uint32_t merge_light = table ? 6u + (uint32_t)(((uint64_t)n * nw) / ((uint64_t)P.nb * ch)) * 2u : 6u;
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
-    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, ACC_LDS_RESERVE, st>>>(d_srs, sorted, gstart, partials, total_buckets, ch);
+    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, ACC_LDS_RESERVE, st>>>(points, sorted, gstart, partials, total_buckets, ch);
     if (tm) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
-    msm_merge_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch);
+    msm_merge_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch, merge_light);
     msm_merge_heavy_kernel<<<1024, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
     if (tm) HIPCHK(hipEventRecord(ev[4], st));
 
@@ -801,32 +872,32 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint64_t* d_scalars, size
     };
     // rows: groups = (window, hi), contiguous length L -> 1.  cols: groups = window, length nb folded by halves of the hi
     // range until L entries (the column sums) remain.
-    Chain rowcol[2] = { { buckets, nw * H, L, 1, L }, { buckets, nw, P.nb, L, P.nb } };
+    Chain rowcol[2] = { { buckets, G * H, L, 1, L }, { buckets, G, P.nb, L, P.nb } };
     run_chains(rowcol, 2);
     const uint32_t* R = rowcol[0].in;  // [nw][H]
     const uint32_t* Cc = rowcol[1].in; // [nw][L]
     if (tm) HIPCHK(hipEventRecord(ev[5], st));
-    uint32_t* trbuf = alloc_pts((size_t)nw * P.hbits * std::max(1u, H / 4));
-    uint32_t* tcbuf = alloc_pts((size_t)nw * std::max(1u, P.lbits) * std::max(1u, L / 4));
+    uint32_t* trbuf = alloc_pts((size_t)G * P.hbits * std::max(1u, H / 4));
+    uint32_t* tcbuf = alloc_pts((size_t)G * std::max(1u, P.lbits) * std::max(1u, L / 4));
     {
         SliceArgs SA{};
         uint32_t nj = 0, mt = 0;
-        if (P.hbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = R; J.out = trbuf; J.groups = nw; J.bits = P.hbits; J.len = H; mt = std::max(mt, nw * P.hbits * std::max(1u, H / 4)); }
-        if (P.lbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = Cc; J.out = tcbuf; J.groups = nw; J.bits = P.lbits; J.len = L; mt = std::max(mt, nw * P.lbits * std::max(1u, L / 4)); }
+        if (P.hbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = R; J.out = trbuf; J.groups = G; J.bits = P.hbits; J.len = H; mt = std::max(mt, G * P.hbits * std::max(1u, H / 4)); }
+        if (P.lbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = Cc; J.out = tcbuf; J.groups = G; J.bits = P.lbits; J.len = L; mt = std::max(mt, G * P.lbits * std::max(1u, L / 4)); }
         if (nj) msm_slice_kernel<<<dim3((mt + MSM_THREADS - 1) / MSM_THREADS, nj), MSM_THREADS, 0, st>>>(SA);
     }
-    Chain zt[3] = { { R, nw, H, 1, H },
-                    { trbuf, nw * P.hbits, std::max(1u, H / 4), 1, std::max(1u, H / 4) },
-                    { tcbuf, nw * std::max(1u, P.lbits), std::max(1u, L / 4), 1, std::max(1u, L / 4) } };
+    Chain zt[3] = { { R, G, H, 1, H },
+                    { trbuf, G * P.hbits, std::max(1u, H / 4), 1, std::max(1u, H / 4) },
+                    { tcbuf, G * std::max(1u, P.lbits), std::max(1u, L / 4), 1, std::max(1u, L / 4) } };
     run_chains(zt, 3);
     if (arena_overflow) {
         (void)hipStreamSynchronize(st);
         set_error("internal: fold arena too small (n=%zu c=%u nw=%u)", n, P.c, nw);
         return BBGPU_ERR_STATE;
     }
-    msm_collect_kernel<<<(nw * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, nw, P.hbits, P.lbits);
+    msm_collect_kernel<<<(G * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, G, P.hbits, P.lbits);
     if (tm) HIPCHK(hipEventRecord(ev[6], st));
-    HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)nw * 64 * 128, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(S.done, st));
     HIPCHK(hipGetLastError());
     S.pending = true;
@@ -901,6 +972,18 @@ int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, 
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipFree(d_tab));
     *d_srs_out = d_srs;
+    return BBGPU_OK;
+}
+
+// builds the pre-shifted window tables for a resident SRS of n points: W x n x 64 bytes
+int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uint32_t** d_tab_out, hipStream_t st)
+{
+    uint32_t* d_tab = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tab, (size_t)num_windows * n * 64));
+    srs_table_kernel<<<(uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(d_srs, d_tab, (uint32_t)n, (uint32_t)c, (uint32_t)num_windows);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    *d_tab_out = d_tab;
     return BBGPU_OK;
 }
 

@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=LOG2N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-window-tables", action="store_true", help="disable the pre-shifted SRS window tables")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
     args = ap.parse_args()
@@ -111,6 +112,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     G = BbGpu(device=local_rank)
+    G.set_precompute(not args.no_window_tables)
     n = 1 << args.log2n
 
     def barrier():
@@ -128,7 +130,7 @@ def main():
         srs, table = G.srs_generate(x_secret, n), None
     scalars = random_field_elements(n, 0xC0FFEE)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
-    W = G.msm_num_windows(n)
+    W = G.srs_num_windows(srs, n)
     wb, we = W * rank // world, W * (rank + 1) // world
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the 96-byte partial sums are exchanged
     gather_buf = [torch.empty(12, dtype=torch.int64, device=xdev) for _ in range(world)] if world > 1 else None
@@ -253,7 +255,8 @@ def main():
             "dtype": "u32x9 (256-bit Montgomery, 29-bit limbs)",
             "data": "synthetic",
             "config": {"workload": "2^%d-point BN254 G1 MSM, uniformly random 253-bit scalars vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
-                       "parallelism": "digit windows [%d) sharded over %d rank(s), one all-gather of 96 B partial sums" % (W, world) if world > 1 else "single GPU, %d windows of 16 bits" % W},
+                       "parallelism": "digit windows [%d) sharded over %d rank(s), one all-gather of 96 B partial sums" % (W, world) if world > 1 else "single GPU, %d windows of 16 bits" % W,
+                       "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
                          "merge": float(stage[4]), "bucket_folds": float(stage[5]), "slices_collect": float(stage[6]),
                          "note": "one MSM at a time (no overlap)"},

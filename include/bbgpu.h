@@ -66,6 +66,14 @@ int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* con
  * it on first sight), so sub-slices `points + 2*off` of a registered table are served from the resident copy
  * (batched_scalar_multiplications slices exactly like that, scalar_multiplication.cpp:720-726). */
 int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
+/* Registration also builds, on the device, the pre-shifted window tables 2^(c w) * P_i (the reference's
+ * generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129): W x n x 64 bytes (1 GiB at n = 2^20), so that
+ * all digit windows share one bucket set.  On by default for 1024 <= n <= 2^20; bbgpu_set_precompute(0) turns it off for
+ * tables registered afterwards.  Results are identical either way. */
+void bbgpu_set_precompute(int enabled);
+/* number of digit windows an MSM of n points against this table is split into (use this, not bbgpu_msm_num_windows, to
+ * shard windows over ranks: a table carries the window size it was built for) */
+int bbgpu_srs_num_windows(int srs_handle, size_t n);
 int bbgpu_srs_release(int handle);
 /* device-side generation of the synthetic SRS x^i * G, i < n, straight into a resident table; optionally also written
  * back to the host as the reference-format 2n endo table (may be NULL).  Stands in for the missing srs_db/transcript.dat */
