@@ -21,6 +21,7 @@
 #include <mutex>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <unordered_map>
 
 #include "bbgpu_internal.h"
@@ -69,6 +70,14 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits)
 {
     return __brev(x) >> (32 - bits);
 }
+// LDS position of element e of a column: XOR swizzle of the five bank bits.  A bijection on [0, 2^k) for every k, found
+// by search: every access pattern of the radix-2^2 stage pairs (strides 4, 16, 64, ...), of the odd last stage and of
+// the natural-order store is bank-conflict free, and the bit-reversed load is <= 2-way (4 at 2048); the unswizzled
+// layout is 4-, 4-, 2-way conflicted in the first three stage pairs and 32-way in the load.
+__device__ __forceinline__ uint32_t lds_pos(uint32_t e)
+{
+    return e ^ ((e >> 2) & 31u) ^ ((e >> 7) & 3u);
+}
 
 struct NttPassArgs {
     const uint32_t* in;       // n x 8 words
@@ -86,6 +95,7 @@ struct NttPassArgs {
     uint32_t out_sa, out_sb;  // result (k, b) is written to out[k * out_sa + b * out_sb]
     uint32_t lo_bits;         // split of the two-level tables
     uint32_t b_fast;          // 1: consecutive threads walk b first (column pass), 0: a first (row pass)
+    uint32_t debug_skip;      // timing experiments only (BBGPU_NTT_SKIP): 1 = skip stages, 2 = skip twist/post multiplies
 };
 
 // FLAGS: 1 = pre-scale input by scale tables (coset_fft), 2 = twist output (pass 1 of 2),
@@ -110,7 +120,7 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
             auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
             x = mul(x, g);
         }
-        const uint32_t pos = c * S + bitrev(a, A.log_s);
+        const uint32_t pos = c * S + lds_pos(bitrev(a, A.log_s));
 #pragma unroll
         for (int l = 0; l < NL; l++) lds[l * E + pos] = x.d[l];
     }
@@ -122,20 +132,21 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
     // Intermediate sums stay lazy (no renormalisation between the two stages); same multiplies as radix-2, half the LDS
     // traffic and half the barriers.
     const uint32_t half = S >> 1;
-    uint32_t s = 0;
+    uint32_t s = (A.debug_skip & 1) ? A.log_s : 0;
     for (; s + 1 < A.log_s; s += 2) {
         const uint32_t m = 1u << s, quarter = S >> 2, ngr = cols * quarter;
         for (uint32_t gq = tid; gq < ngr; gq += NTT_THREADS) {
             const uint32_t c = gq >> (A.log_s - 2), q = gq & (quarter - 1);
             const uint32_t j = q & (m - 1);
-            const uint32_t e0 = c * S + (((q >> s) << (s + 2)) | j);
+            const uint32_t i0 = ((q >> s) << (s + 2)) | j, cb = c * S;
+            const uint32_t e0 = cb + lds_pos(i0), e1 = cb + lds_pos(i0 + m), e2 = cb + lds_pos(i0 + 2 * m), e3 = cb + lds_pos(i0 + 3 * m);
             FrL x0, x1, x2, x3;
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 x0.d[l] = lds[l * E + e0];
-                x1.d[l] = lds[l * E + e0 + m];
-                x2.d[l] = lds[l * E + e0 + 2 * m];
-                x3.d[l] = lds[l * E + e0 + 3 * m];
+                x1.d[l] = lds[l * E + e1];
+                x2.d[l] = lds[l * E + e2];
+                x3.d[l] = lds[l * E + e3];
             }
             // stage s
             Fe<Fr, 2, NTT_VMAX + 3> a0, a2;
@@ -165,9 +176,9 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 lds[l * E + e0] = y0.d[l];
-                lds[l * E + e0 + m] = y1.d[l];
-                lds[l * E + e0 + 2 * m] = y2.d[l];
-                lds[l * E + e0 + 3 * m] = y3.d[l];
+                lds[l * E + e1] = y1.d[l];
+                lds[l * E + e2] = y2.d[l];
+                lds[l * E + e3] = y3.d[l];
             }
         }
         __syncthreads();
@@ -177,7 +188,8 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
         for (uint32_t bf = tid; bf < nbf; bf += NTT_THREADS) {
             const uint32_t c = bf >> (A.log_s - 1), i = bf & (half - 1);
             const uint32_t j = i & (m - 1);
-            const uint32_t lo = c * S + (((i >> s) << (s + 1)) | j), hi = lo + m;
+            const uint32_t il = ((i >> s) << (s + 1)) | j;
+            const uint32_t lo = c * S + lds_pos(il), hi = c * S + lds_pos(il + m);
             FrL x, y;
 #pragma unroll
             for (int l = 0; l < NL; l++) {
@@ -210,10 +222,12 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
         const uint32_t b = b0 + c;
         FrL x;
 #pragma unroll
-        for (int l = 0; l < NL; l++) x.d[l] = lds[l * E + c * S + k];
+        for (int l = 0; l < NL; l++) x.d[l] = lds[l * E + c * S + lds_pos(k)];
         const size_t gidx = (size_t)k * A.out_sa + (size_t)b * A.out_sb;
         uint32_t w[8];
-        if constexpr (FLAGS & 2) {
+        if ((A.debug_skip & 2) != 0) {
+            pack(assume_bound<1, 2>(x), w);
+        } else if constexpr (FLAGS & 2) {
             const uint32_t ex = b * k; // < n
             auto tw = mul(load_tw(A.twist_lo, ex & ((1u << A.lo_bits) - 1)), load_tw(A.twist_hi, ex >> A.lo_bits));
             auto r = mul(x, tw); // 48 * 2 / 169 + 2 = 2  -> fits 256 bits
@@ -424,6 +438,7 @@ int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, con
 
     const uint32_t n1 = 1u << D->log_s1, n2 = 1u << D->log_s2;
     NttPassArgs A{};
+    if (const char* e = getenv("BBGPU_NTT_SKIP")) A.debug_skip = (uint32_t)atoi(e);
     A.lo_bits = D->lo_bits;
     A.twist_lo = D->twist_lo[inverse];
     A.twist_hi = D->twist_hi[inverse];
