@@ -46,7 +46,8 @@ class BbGpuError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "libbbgpu.so")
+    # BBGPU_LIB: alternative build of the same library (A/B timing of kernel variants); default = the in-tree build
+    return os.environ.get("BBGPU_LIB") or os.path.join(HERE, "libbbgpu.so")
 
 
 def build_library(force=False):

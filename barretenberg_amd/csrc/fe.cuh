@@ -156,6 +156,21 @@ template <class F, int L, int V> BB_HD Fe<F, 1, V> carry_full(const Fe<F, L, V>&
 
 // ---- Montgomery multiplication, R = 2^261 -----------------------------------------------------------------------
 // every column sum is <= 9*(L1*U)*(L2*U) + 9*2^58 + carry < 2^64 whenever L1*L2 <= 6.
+// acc = a*b + c.  LLVM sums a column's products first and adds the incoming carry with a separate v_lshl_add_u64
+// (17 per multiplication).  Forcing the carry into the first v_mad_u64_u32 with an asm statement removes them and was
+// measured at +2..5 % in the bare multiplier loop (tools/ubench/ubench_mul2.hip) but within noise (< 1 %) on the MSM and
+// NTT kernels, so the plain expression stays; define BBGPU_ASM_MAD to get the asm form.
+BB_HD uint64_t mad_carry_in(uint32_t a, uint32_t b, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BBGPU_ASM_MAD)
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return r;
+#else
+    return (uint64_t)a * b + c;
+#endif
+}
+
 // Fused product scanning: one 64-bit accumulator walks the 18 columns; the carry out of column k is the addend of the
 // first multiply-add of column k+1, so there is no column array and no 64-bit carry addition.
 template <class F> BB_HD void mul_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], uint32_t (&out)[NL])
@@ -164,8 +179,9 @@ template <class F> BB_HD void mul_raw(const uint32_t (&a)[NL], const uint32_t (&
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; k++) {
+        acc = mad_carry_in(a[0], b[k], acc);
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)a[i] * b[k - i];
+        for (int i = 1; i <= k; i++) acc += (uint64_t)a[i] * b[k - i];
 #pragma unroll
         for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::P[k - i];
         m[k] = ((uint32_t)acc * F::PINV) & M29;
@@ -174,8 +190,9 @@ template <class F> BB_HD void mul_raw(const uint32_t (&a)[NL], const uint32_t (&
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; k++) {
+        acc = mad_carry_in(a[k - (NL - 1)], b[NL - 1], acc);
 #pragma unroll
-        for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)a[i] * b[k - i];
+        for (int i = k - (NL - 1) + 1; i < NL; i++) acc += (uint64_t)a[i] * b[k - i];
 #pragma unroll
         for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)m[i] * F::P[k - i];
         out[k - NL] = (uint32_t)acc & M29;
@@ -192,12 +209,19 @@ template <class F> BB_HD void sqr_raw(const uint32_t (&a)[NL], uint32_t (&out)[N
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
+        // first product of the column takes the carry as its addend: the square term on even columns, else the first cross term
+        if ((k & 1) == 0) {
+            acc = mad_carry_in(a[k / 2], a[k / 2], acc);
+        } else {
+            const int i0 = k < NL ? 0 : k - (NL - 1);
+            acc = mad_carry_in(a2[i0], a[k - i0], acc);
+        }
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int j = k - i;
-            if (j > i && j < NL) acc += (uint64_t)a2[i] * a[j];
+            const int i0 = k < NL ? 0 : k - (NL - 1);
+            if (j > i && j < NL && !((k & 1) == 1 && i == i0)) acc += (uint64_t)a2[i] * a[j];
         }
-        if ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
         if (k < NL) {
 #pragma unroll
             for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::P[k - i];
@@ -222,8 +246,10 @@ BB_HD void mul2_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; k++) {
+        acc = mad_carry_in(a[0], b[k], acc);
+        acc += (uint64_t)c[0] * d[k];
 #pragma unroll
-        for (int i = 0; i <= k; i++) {
+        for (int i = 1; i <= k; i++) {
             acc += (uint64_t)a[i] * b[k - i];
             acc += (uint64_t)c[i] * d[k - i];
         }
@@ -235,8 +261,10 @@ BB_HD void mul2_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; k++) {
+        acc = mad_carry_in(a[k - (NL - 1)], b[NL - 1], acc);
+        acc += (uint64_t)c[k - (NL - 1)] * d[NL - 1];
 #pragma unroll
-        for (int i = k - (NL - 1); i < NL; i++) {
+        for (int i = k - (NL - 1) + 1; i < NL; i++) {
             acc += (uint64_t)a[i] * b[k - i];
             acc += (uint64_t)c[i] * d[k - i];
         }
