@@ -287,23 +287,42 @@ __global__ void __launch_bounds__(SORT_THREADS) sortA_hist_kernel(const int16_t*
     if (threadIdx.x < bins) histA[((size_t)wl * slices + s) * bins + threadIdx.x] = lh[threadIdx.x];
 }
 
-// per group (one block, one thread per bin, bins <= 1024): cursors relative to the bin start (exclusive over slices), local bin
-// starts (exclusive over bins) and the window's entry count
-__global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ binstart,
-                                                                uint32_t* __restrict__ totals, uint32_t bins, uint32_t slices)
+// Column scan of the pass-A histogram matrix [slices][bins] of one group: for every bin the exclusive prefix over slices
+// (cursors relative to the bin start, in place) and the bin total.  16 bins per block, one wave per bin, each lane owns
+// a run of slices and the wave combines them with shuffles (a single thread walking hundreds of slices was latency-bound).
+__global__ void __launch_bounds__(SORT_THREADS) sortA_colscan_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ bintot, uint32_t bins,
+                                                                   uint32_t slices)
+{
+    const uint32_t wl = blockIdx.y, lane = threadIdx.x & 63;
+    const uint32_t bin = blockIdx.x * (SORT_THREADS / 64) + (threadIdx.x >> 6);
+    if (bin >= bins) return; // whole waves exit together
+    uint32_t* H = histA + (size_t)wl * slices * bins + bin;
+    const uint32_t spp = (slices + 63) / 64;
+    const uint32_t s0 = min(slices, lane * spp), s1 = min(slices, s0 + spp);
+    uint32_t sum = 0;
+    for (uint32_t s = s0; s < s1; s++) sum += H[(size_t)s * bins];
+    uint32_t incl = sum; // inclusive scan over the 64 lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += v;
+    }
+    uint32_t run = incl - sum;
+    for (uint32_t s = s0; s < s1; s++) {
+        const uint32_t cnt = H[(size_t)s * bins];
+        H[(size_t)s * bins] = run;
+        run += cnt;
+    }
+    if (lane == 63) bintot[(size_t)wl * bins + bin] = incl;
+}
+// per group: exclusive scan of the bin totals -> local bin starts, and the group's entry count (bins <= 1024)
+__global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(const uint32_t* __restrict__ bintot, uint32_t* __restrict__ binstart,
+                                                                uint32_t* __restrict__ totals, uint32_t bins)
 {
     __shared__ uint32_t part[SORT_THREADS];
     const uint32_t wl = blockIdx.x, t = threadIdx.x;
-    uint32_t run = 0;
-    if (t < bins) {
-        uint32_t* H = histA + (size_t)wl * slices * bins + t;
-        for (uint32_t s = 0; s < slices; s++) {
-            const uint32_t cnt = H[(size_t)s * bins];
-            H[(size_t)s * bins] = run;
-            run += cnt;
-        }
-    }
-    part[t] = run;
+    const uint32_t mine = t < bins ? bintot[(size_t)wl * bins + t] : 0;
+    part[t] = mine;
     __syncthreads();
     for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
         uint32_t v = t >= off ? part[t - off] : 0;
@@ -311,7 +330,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(uint32_t* __re
         part[t] += v;
         __syncthreads();
     }
-    if (t < bins) binstart[(size_t)wl * bins + t] = part[t] - run;
+    if (t < bins) binstart[(size_t)wl * bins + t] = part[t] - mine;
     if (t == SORT_THREADS - 1) totals[wl] = part[SORT_THREADS - 1];
 }
 // window bases (exclusive prefix of the window totals), M = total number of entries -> gstart[total_buckets]
@@ -716,6 +735,7 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     tot += al((size_t)P.W * n * 2);                          // digits
     tot += al((size_t)nw * P.slices * 1024 * 4);             // pass-A histogram / cursors (<= 1024 bins)
     tot += al((size_t)nw * 1024 * 4 + 256);                  // bin starts
+    tot += al((size_t)nw * 1024 * 4 + 256);                  // bin totals
     tot += al((size_t)nw * n * 4);                           // pass-A output
     tot += al(((size_t)nw * P.nb + 1) * 4);                  // gstart
     tot += al((size_t)nw * 8 + 512);                         // totals, bases (nw + 1)
@@ -780,7 +800,8 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     uint32_t sort_lb = P.sort_lb, sort_bins = P.sort_bins;
     if (table)
         while (sort_bins < 1024 && sort_lb > 3) { sort_lb--; sort_bins <<= 1; }
-    const uint32_t slices = table ? std::max<uint32_t>(1, P.slices * nw / 2) : P.slices;
+    uint32_t slices = table ? std::max<uint32_t>(1, P.slices * nw / 2) : P.slices;
+    if (const char* e = getenv("BBGPU_SLICES")) slices = std::min<uint32_t>(std::max(1, atoi(e)), P.slices * nw); // tuning knob
     const uint32_t slice_len = (uint32_t)((n + slices - 1) / slices);
     const uint32_t idx_stride = table ? (uint32_t)tab_stride : 0u;
     const uint32_t* points = table ? d_tab : d_srs;
@@ -795,6 +816,7 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     int16_t* digits = (int16_t*)p; p += al((size_t)P.W * n * 2);
     uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * 1024 * 4);
     uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
+    uint32_t* bintot = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
     uint32_t* tmp_entries = (uint32_t*)p; p += al((size_t)nw * n * 4);
     uint32_t* gstart = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
     uint32_t* totals = (uint32_t*)p; uint32_t* bases = totals + nw; p += al((size_t)nw * 8 + 512);
@@ -821,7 +843,8 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
     sortA_hist_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
-    sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(histA, binstart, totals, sort_bins, slices);
+    sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
+    sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
     sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
     sortA_scatter_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
                                                                    slice_len, (uint32_t)wb, wpg, idx_stride);
