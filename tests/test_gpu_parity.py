@@ -233,6 +233,46 @@ def test_msm_window_sharding_adds_up(gpu, oracle, msm_small):
         assert np.array_equal(gpu.g1_sum(np.stack(partials)), full), parts
 
 
+def test_msm_skewed_scalars(gpu, oracle, msm_small):
+    """digit distributions far from uniform (what real witnesses look like): every scalar equal, scalars in {0, 1, -1},
+    tiny scalars -- exercises the heavy-bucket merge path (one bucket cut into thousands of chunk partials)"""
+    g, srs, table, scalars = msm_small
+    n = 1 << 14
+    one = oracle.const(FR, "one")
+    minus_one = oracle.neg(FR, one)
+    rng = np.random.default_rng(5)
+    sets = {
+        "all equal": np.tile(scalars[7], (n, 1)),
+        "0/1/-1": np.stack([(np.zeros(4, dtype=np.uint64), one, minus_one)[i] for i in rng.integers(0, 3, n)]),
+        "small": np.stack([oracle.to_mont(FR, np.array([int(v), 0, 0, 0], dtype=np.uint64)) for v in rng.integers(0, 200, n)]),
+    }
+    for name, sc in sets.items():
+        sc = aligned_copy(sc)
+        want = oracle.msm_affine(sc, table, n)
+        got = gpu.pippenger(sc, table, n)
+        assert np.array_equal(got[:8], want[:8]), name
+        assert (int(got[7]) >> 63) == (int(want[7]) >> 63), name
+
+
+def test_msm_additivity_large(gpu, oracle):
+    """sizes beyond the golden fixtures (non-power-of-two, and 2^21 which exceeds the window-table limit):
+    MSM(n) == MSM(first half) + MSM(second half), through independent code paths (different n => different chunking)"""
+    import torch
+    x = oracle.random_scalars(SRS_SEED + 1, 1)[0]
+    for n in (3 << 18, 1 << 21):
+        h = gpu.srs_generate(x, n)
+        sc = np.random.default_rng(n).integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+        sc[:, 3] &= np.uint64(0x1FFFFFFFFFFFFFFF)
+        d = torch.from_numpy(sc.view(np.int64)).cuda()
+        full = gpu.msm_device(h, d.data_ptr(), n)
+        m = n // 2 + 12345
+        lo = gpu.msm_device(h, d.data_ptr(), m)
+        hi = gpu.msm_device(h, d.data_ptr() + m * 32, n - m, offset=m)
+        assert np.array_equal(gpu.g1_sum(np.stack([lo, hi])), full), n
+        assert not (int(full[7]) >> 63)
+        gpu.srs_release(h)
+
+
 def test_msm_async_pipeline(gpu, oracle, msm_small):
     """two MSMs in flight (bbgpu_msm_g1_device_async / _wait): results independent of the overlap"""
     import torch
