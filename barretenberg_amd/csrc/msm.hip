@@ -267,7 +267,7 @@ constexpr uint32_t SORT_MAX_LB = 7;
 
 // A "group" is a set of `wpg` consecutive windows that share one bucket set: 1 window per group normally, all windows of
 // the call in one group when the SRS carries pre-shifted window tables (the window weight is then baked into the point).
-__global__ void __launch_bounds__(SORT_THREADS) sortA_hist_kernel(const int16_t* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
+__global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const int16_t* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
                                                                 uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0,
                                                                 uint32_t wpg)
 {
@@ -347,7 +347,7 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
     }
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) sortA_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursorsA,
+__global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursorsA,
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                    uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
                                                                    uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
