@@ -1,0 +1,132 @@
+// plonk_driver.cpp -- TEST INFRASTRUCTURE ONLY (BASELINE config 5).
+//
+// Our own driver around the reference's UNMODIFIED PLONK stack (StandardComposer -> waffle::Prover -> waffle::Verifier),
+// compiled where the reference sources lie by oracle/Makefile into two executables:
+//   oracle/_ref/plonk_cpu : everything from the reference (its x86-64 asm MSM / FFT)                      -> golden proof
+//   oracle/_ref/plonk_gpu : same objects, but pippenger / batched_scalar_multiplications / the fft family are
+//                           localised away (objcopy) and resolved by barretenberg_amd/libbbshim.so -> libbbgpu.so (MI355X)
+// Both print the proof (9 affine commitments + 12 field evaluations, waffle_types.hpp:18-45) as hex; a drop-in GPU path
+// must print byte-identical output (Fiat-Shamir challenges hash the commitments, challenge.hpp:15-135).
+//
+//   plonk_xxx transcript <path> <num_points>   write a synthetic SRS in the reference's transcript format (io.hpp:36-182)
+//   plonk_xxx prove <num_gates>                build the add/mul-chain circuit of test/benchmarks/bench_plonk.cpp:25-37 with
+//                                              fixed witnesses, prove, verify, print
+#include <barretenberg/curves/bn254/fq.hpp>
+#include <barretenberg/curves/bn254/fr.hpp>
+#include <barretenberg/curves/bn254/g1.hpp>
+#include <barretenberg/curves/bn254/g2.hpp>
+#include <barretenberg/waffle/composer/standard_composer.hpp>
+#include <barretenberg/waffle/proof_system/preprocess.hpp>
+#include <barretenberg/waffle/proof_system/prover/prover.hpp>
+#include <barretenberg/waffle/proof_system/verifier/verifier.hpp>
+#include <barretenberg/waffle/stdlib/field/field.hpp>
+
+#include <arpa/inet.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace barretenberg;
+
+namespace {
+// the synthetic SRS secret (fixed, public: this is a test SRS)
+fr::field_t secret()
+{
+    fr::field_t x = { { 0x0123456789abcdefULL, 0xfedcba9876543210ULL, 0x0f1e2d3c4b5a6978ULL, 0x0123456789abcdefULL } };
+    return fr::to_montgomery_form(x);
+}
+void put_fq(std::vector<unsigned char>& out, const fq::field_t& mont)
+{
+    fq::field_t v = fq::from_montgomery_form(mont); // file holds non-Montgomery limbs, each big-endian, limb 0 first
+    for (int l = 0; l < 4; l++)
+        for (int b = 7; b >= 0; b--) out.push_back((unsigned char)(v.data[l] >> (8 * b)));
+}
+void put_u32(std::vector<unsigned char>& out, uint32_t v)
+{
+    uint32_t be = htonl(v);
+    unsigned char* p = (unsigned char*)&be;
+    out.insert(out.end(), p, p + 4);
+}
+
+int write_transcript(const char* path, size_t num)
+{
+    const fr::field_t x = secret();
+    std::vector<unsigned char> out;
+    // io.hpp:36-46: transcript_number, total_transcripts, total_g1_points, total_g2_points, num_g1_points, num_g2_points, start_from
+    put_u32(out, 0); put_u32(out, 1); put_u32(out, (uint32_t)num); put_u32(out, 2); put_u32(out, (uint32_t)num); put_u32(out, 2); put_u32(out, 0);
+    g1::affine_element p = g1::group_exponentiation(g1::affine_one(), x); // file point k = x^(k+1) G
+    for (size_t k = 0; k < num; k++) {
+        put_fq(out, p.x);
+        put_fq(out, p.y);
+        if (k + 1 < num) p = g1::group_exponentiation(p, x);
+    }
+    g2::affine_element h = g2::affine_one();
+    g2::affine_element hx = g2::group_exponentiation(h, x);
+    const g2::affine_element g2pts[2] = { h, hx }; // index 1 must be x * G2 (io.hpp:171-180)
+    for (const auto& q : g2pts) {
+        put_fq(out, q.x.c0); put_fq(out, q.x.c1); put_fq(out, q.y.c0); put_fq(out, q.y.c1);
+    }
+    out.insert(out.end(), 64, 0); // checksum slot, never verified by the reference
+    FILE* f = fopen(path, "wb");
+    if (!f) return 1;
+    fwrite(out.data(), 1, out.size(), f);
+    fclose(f);
+    printf("wrote %zu G1 points + 2 G2 points to %s\n", num, path);
+    return 0;
+}
+
+void hex4(const char* name, const uint64_t* d)
+{
+    printf("%s %016lx%016lx%016lx%016lx\n", name, d[3], d[2], d[1], d[0]);
+}
+
+int prove(size_t num_gates)
+{
+    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
+    fr::field_t a0 = fr::to_montgomery_form({ { 0x1111111122222222ULL, 0x3333333344444444ULL, 0x5555555566666666ULL, 0x0777777788888888ULL } });
+    fr::field_t b0 = fr::to_montgomery_form({ { 0x9999aaaabbbbccccULL, 0xddddeeeeffff0000ULL, 0x1234123412341234ULL, 0x0abcdefabcdefabcULL } });
+    plonk::stdlib::field_t a(plonk::stdlib::witness_t(&composer, a0));
+    plonk::stdlib::field_t b(plonk::stdlib::witness_t(&composer, b0));
+    plonk::stdlib::field_t c(&composer);
+    for (size_t i = 0; i < (num_gates / 4) - 4; ++i) { // bench_plonk.cpp:30-36
+        c = a + b;
+        c = a * c;
+        a = b * b;
+        b = c * c;
+    }
+    waffle::Prover prover = composer.preprocess();
+    waffle::Verifier verifier = waffle::preprocess(prover);
+    auto t0 = std::chrono::steady_clock::now();
+    waffle::plonk_proof proof = prover.construct_proof();
+    auto t1 = std::chrono::steady_clock::now();
+    bool ok = verifier.verify_proof(proof);
+    printf("n %zu\n", prover.n);
+    const g1::affine_element* pts[9] = { &proof.W_L, &proof.W_R, &proof.W_O, &proof.Z_1, &proof.T_LO, &proof.T_MID, &proof.T_HI, &proof.PI_Z, &proof.PI_Z_OMEGA };
+    const char* pn[9] = { "W_L", "W_R", "W_O", "Z_1", "T_LO", "T_MID", "T_HI", "PI_Z", "PI_Z_OMEGA" };
+    for (int i = 0; i < 9; i++) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "%s.x", pn[i]); hex4(nm, pts[i]->x.data);
+        snprintf(nm, sizeof nm, "%s.y", pn[i]); hex4(nm, pts[i]->y.data);
+    }
+    const fr::field_t* ev[12] = { &proof.w_l_eval, &proof.w_r_eval, &proof.w_o_eval, &proof.sigma_1_eval, &proof.sigma_2_eval, &proof.z_1_shifted_eval,
+                                  &proof.linear_eval, &proof.w_l_shifted_eval, &proof.w_r_shifted_eval, &proof.w_o_shifted_eval, &proof.q_c_eval,
+                                  &proof.q_mimc_coefficient_eval };
+    const char* en[12] = { "w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval", "w_l_shifted_eval",
+                           "w_r_shifted_eval", "w_o_shifted_eval", "q_c_eval", "q_mimc_coefficient_eval" };
+    for (int i = 0; i < 7; i++) hex4(en[i], ev[i]->data); // the standard arithmetic circuit fills these; the rest stay unset
+    (void)en; (void)ev;
+    printf("verified %d\n", ok ? 1 : 0);
+    fprintf(stderr, "construct_proof %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
+    return ok ? 0 : 2;
+}
+} // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc >= 4 && !strcmp(argv[1], "transcript")) return write_transcript(argv[2], (size_t)atol(argv[3]));
+    if (argc >= 3 && !strcmp(argv[1], "prove")) return prove((size_t)atol(argv[2]));
+    fprintf(stderr, "usage: %s transcript <path> <num_points> | prove <num_gates>\n", argv[0]);
+    return 64;
+}

@@ -325,3 +325,26 @@ def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
     # host-pointer path resolves to the same resident table
     out2 = gpu.pippenger(scalars, table, n)
     assert np.array_equal(out, out2)
+
+
+# ------------------------------------------------------------------ config 5: the reference prover on the GPU ----------
+@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536])
+def test_reference_prover_runs_on_gpu_bit_exact(golden, gates):
+    """BASELINE config 5.  oracle/_ref/plonk_gpu is the reference's UNMODIFIED StandardComposer -> waffle::Prover -> Verifier,
+    compiled in the build container from the reference sources where they lie, with pippenger / batched_scalar_multiplications /
+    the fft family resolved by barretenberg_amd/libbbshim.so -> libbbgpu.so (the INTEGRATION.md link recipe).  Its proof must be
+    byte-identical to the one the all-CPU reference build produced for the same circuit and SRS, and must verify."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "plonk_gpu")
+    srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
+    if not (os.path.exists(exe) and os.path.exists(srs)):
+        pytest.skip("oracle/_ref/plonk_gpu not built (needs /root/reference at build time)")
+    env = dict(os.environ, OMP_NUM_THREADS="16")  # the prover's own CPU loops: do not spawn one thread per host core of the box
+    r = subprocess.run([exe, "prove", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = r.stdout.strip().split("\n")
+    want = golden("plonk_proofs.json")["proofs"][str(gates)]
+    assert got == want
+    assert got[-1] == "verified 1"
