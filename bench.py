@@ -274,7 +274,6 @@ def main():
                                  "kernel": "ntt_pass_kernel x2"}},
         }
         if not args.no_cpu_baseline:
-            from oracle.pyoracle import aligned_copy  # cpu_baseline leg only
             # expected NTT output comes from the reference run inside cpu_baseline; pass the GPU's so it can compare
             cb = cpu_baseline(table, scalars, res[:8], ntt_in, ntt_out)
             line["cpu_baseline"] = cb
