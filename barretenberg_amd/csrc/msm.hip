@@ -683,8 +683,16 @@ struct MsmPlan {
 // K4 residency: 3 workgroups of 256 lanes per CU (3 waves per SIMD; v_mad_u64_u32 issue saturates at 2).  The 4th slot is
 // deliberately left free -- enforced by a dynamic-LDS reservation -- so that the short latency-bound kernels of the
 // previous MSM's tail (merge, folds) can run beside the accumulation of the next one (two-slot pipeline).
-constexpr uint32_t ACC_WG_PER_CU = 3;
 constexpr uint32_t ACC_LDS_RESERVE = 41 * 1024; // 3 x 41 KiB fit in 160 KiB, 4 do not
+static uint32_t acc_wg_per_cu()
+{
+    static int v = 0;
+    if (!v) {
+        v = 3;
+        if (const char* e = getenv("BBGPU_ACC_WGS")) v = std::min(4, std::max(1, atoi(e))); // tuning knob (4 = no reservation)
+    }
+    return (uint32_t)v;
+}
 static uint32_t acc_capacity_lanes()
 {
     static uint32_t lanes = 0;
@@ -692,7 +700,7 @@ static uint32_t acc_capacity_lanes()
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        lanes = (uint32_t)cus * ACC_WG_PER_CU * MSM_THREADS;
+        lanes = (uint32_t)cus * acc_wg_per_cu() * MSM_THREADS;
     }
     return lanes;
 }
@@ -859,7 +867,7 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     // in-lane merge limit: with one shared bucket set every bucket is cut into ~ n*nw / (nb*ch) + 1 partials
     const uint32_t merge_light = table ? 6u + (uint32_t)(((uint64_t)n * nw) / ((uint64_t)P.nb * ch)) * 2u : 6u;
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
-    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, ACC_LDS_RESERVE, st>>>(points, sorted, gstart, partials, total_buckets, ch);
+    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch);
     if (tm) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
     msm_merge_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch, merge_light);
