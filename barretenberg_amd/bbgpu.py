@@ -38,6 +38,11 @@ C_ABI_SYMBOLS = [
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing",
     "bbgpu_set_timing",
+    "bbgpu_fr_evaluate_device", "bbgpu_fr_batch_invert_device", "bbgpu_fr_product_scan_device", "bbgpu_fr_mul_device",
+    "bbgpu_kate_opening_device", "bbgpu_lagrange_l1_fft_device", "bbgpu_divide_by_pseudo_vanishing_device",
+    "bbgpu_permutation_lagrange_base_device",
+    "bbgpu_plonk_prover_create", "bbgpu_plonk_prover_set_witness", "bbgpu_plonk_construct_proof", "bbgpu_plonk_last_challenges",
+    "bbgpu_plonk_last_timing", "bbgpu_plonk_prover_destroy", "bbgpu_plonk_challenges_from_proof",
 ]
 
 
@@ -91,6 +96,15 @@ class BbGpu:
         L.bbgpu_msm_g1_wait.argtypes = [C.c_int, u64p]
         L.bbgpu_g1_sum.argtypes = [u64p, C.c_size_t, u64p]
         L.bbgpu_last_timing.argtypes = [C.POINTER(C.c_float), C.c_int]
+        vp, sz = C.c_void_p, C.c_size_t
+        L.bbgpu_fr_evaluate_device.argtypes = [vp, sz, u64p, u64p, vp]
+        L.bbgpu_fr_batch_invert_device.argtypes = [vp, sz, vp]
+        L.bbgpu_fr_product_scan_device.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp]
+        L.bbgpu_fr_mul_device.argtypes = [vp, vp, vp, sz, vp]
+        L.bbgpu_kate_opening_device.argtypes = [vp, vp, sz, u64p, u64p, vp]
+        L.bbgpu_lagrange_l1_fft_device.argtypes = [vp, sz, sz, vp]
+        L.bbgpu_divide_by_pseudo_vanishing_device.argtypes = [vp, sz, sz, vp]
+        L.bbgpu_permutation_lagrange_base_device.argtypes = [vp, vp, sz, vp]
         self.device = device
         if init:
             self._chk(L.bbgpu_init(device))
@@ -129,6 +143,43 @@ class BbGpu:
         kind = NTT_KINDS[kind] if isinstance(kind, str) else kind
         cp = _ptr(np.ascontiguousarray(constant, dtype=np.uint64)) if constant is not None else None
         self._chk(self.lib.bbgpu_ntt_device(C.c_void_p(d_ptr), n, kind, cp, C.c_void_p(stream or 0)))
+
+    # ---- the O(n) helpers between transforms and commitments, on device-resident vectors (raw device pointers) -----
+    def evaluate_device(self, d_coeffs, n, z, stream=None):
+        """polynomial_arithmetic::evaluate (polynomial_arithmetic.cpp:337-373)"""
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(self.lib.bbgpu_fr_evaluate_device(d_coeffs, n, _ptr(np.ascontiguousarray(z, dtype=np.uint64)), _ptr(out), stream or 0))
+        return out
+
+    def batch_invert_device(self, d_values, n, stream=None):
+        """fr::batch_invert (fields/field.hpp:503-522), in place"""
+        self._chk(self.lib.bbgpu_fr_batch_invert_device(d_values, n, stream or 0))
+
+    def product_scan_device(self, d_in, d_out, n, reverse=False, inclusive=False, stream=None):
+        """running products (prover.cpp:194-202 is the exclusive prefix form)"""
+        self._chk(self.lib.bbgpu_fr_product_scan_device(d_in, d_out, n, int(reverse), int(inclusive), stream or 0))
+
+    def mul_device(self, d_out, d_a, d_b, n, stream=None):
+        """polynomial_arithmetic::mul (:328-335)"""
+        self._chk(self.lib.bbgpu_fr_mul_device(d_out, d_a, d_b, n, stream or 0))
+
+    def compute_kate_opening_coefficients_device(self, d_src, d_dest, n, z, stream=None):
+        """polynomial_arithmetic::compute_kate_opening_coefficients (:562-591); returns F(z)"""
+        f = np.zeros(4, dtype=np.uint64)
+        self._chk(self.lib.bbgpu_kate_opening_device(d_src, d_dest, n, _ptr(np.ascontiguousarray(z, dtype=np.uint64)), _ptr(f), stream or 0))
+        return f
+
+    def compute_lagrange_polynomial_fft_device(self, d_l_1, n_src, n_target, stream=None):
+        """polynomial_arithmetic::compute_lagrange_polynomial_fft (:381-476)"""
+        self._chk(self.lib.bbgpu_lagrange_l1_fft_device(d_l_1, n_src, n_target, stream or 0))
+
+    def divide_by_pseudo_vanishing_polynomial_device(self, d_coeffs, n_src, n_target, stream=None):
+        """polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial (:478-560), in place"""
+        self._chk(self.lib.bbgpu_divide_by_pseudo_vanishing_device(d_coeffs, n_src, n_target, stream or 0))
+
+    def compute_permutation_lagrange_base_single_device(self, d_out, d_mapping, n, stream=None):
+        """waffle::compute_permutation_lagrange_base_single (permutation.hpp:15-87)"""
+        self._chk(self.lib.bbgpu_permutation_lagrange_base_device(d_out, d_mapping, n, stream or 0))
 
     # ---- scalar_multiplication ------------------------------------------------------------------------------------
     def srs_register(self, points_endo_table):

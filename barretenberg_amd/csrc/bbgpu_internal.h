@@ -47,4 +47,7 @@ int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st);
 int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);
 
+// plonk.hip
+void plonk_release_all();
+
 } // namespace bbgpu

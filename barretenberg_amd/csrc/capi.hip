@@ -11,6 +11,7 @@
 
 #include "bbgpu_internal.h"
 #include "host_g1.hpp"
+#include "poly.h"
 
 namespace bbgpu {
 
@@ -49,6 +50,9 @@ struct Context {
     size_t scratch_cap = 0;
     bool timing = false;
     bool precompute = true; // build window tables for registered SRS (bbgpu_set_precompute)
+    poly::Scratch poly_scratch; // workspace of the resident polynomial helpers
+    uint64_t* d_poly_tmp = nullptr;
+    size_t poly_tmp_cap = 0;
     MsmTiming last;
 };
 
@@ -213,7 +217,12 @@ void bbgpu_shutdown(void)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g_ctx.ready) return;
+    plonk_release_all();
     (void)hipStreamSynchronize(g_ctx.stream);
+    g_ctx.poly_scratch.release();
+    if (g_ctx.d_poly_tmp) (void)hipFree(g_ctx.d_poly_tmp);
+    g_ctx.d_poly_tmp = nullptr;
+    g_ctx.poly_tmp_cap = 0;
     for (auto& e : g_ctx.srs) {
         if (e.live && e.d_srs) (void)hipFree(e.d_srs);
         if (e.live && e.d_tab) (void)hipFree(e.d_tab);
@@ -285,6 +294,112 @@ int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
     CHK(hipMemcpyAsync(coeffs, g_ctx.d_stage, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
     CHK(hipStreamSynchronize(g_ctx.stream));
     return BBGPU_OK;
+}
+
+/* ---- resident polynomial helpers ---- */
+#define POLY_ENTER(ptr_ok)                                                                                              \
+    std::lock_guard<std::recursive_mutex> lk(g_mu);                                                                     \
+    {                                                                                                                   \
+        int rc_ = ensure_init();                                                                                        \
+        if (rc_) return rc_;                                                                                            \
+        if (!(ptr_ok)) {                                                                                                \
+            set_error("null device pointer");                                                                           \
+            return BBGPU_ERR_ARG;                                                                                       \
+        }                                                                                                               \
+    }                                                                                                                   \
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream
+
+static host::Fr load_fr(const uint64_t z[4])
+{
+    host::Fr r;
+    memcpy(r.d, z, 32);
+    return r;
+}
+
+int bbgpu_fr_evaluate_device(const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4], void* hip_stream)
+{
+    POLY_ENTER((d_coeffs || n == 0) && z && out);
+    host::Fr r;
+    int rc = poly::evaluate(d_coeffs, n, load_fr(z), &r, g_ctx.poly_scratch, st);
+    if (rc) return rc;
+    memcpy(out, r.d, 32);
+    return BBGPU_OK;
+}
+
+int bbgpu_fr_batch_invert_device(uint64_t* d_values, size_t n, void* hip_stream)
+{
+    POLY_ENTER(d_values || n == 0);
+    int rc = grow(&g_ctx.d_poly_tmp, &g_ctx.poly_tmp_cap, n * 32);
+    if (rc) return rc;
+    return poly::batch_invert(d_values, g_ctx.d_poly_tmp, n, g_ctx.poly_scratch, st);
+}
+
+int bbgpu_fr_product_scan_device(const uint64_t* d_in, uint64_t* d_out, size_t n, int reverse, int inclusive, void* hip_stream)
+{
+    POLY_ENTER((d_in && d_out) || n == 0);
+    return poly::product_scan(d_in, d_out, n, reverse != 0, inclusive != 0, g_ctx.poly_scratch, st, nullptr);
+}
+
+int bbgpu_fr_mul_device(uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n, void* hip_stream)
+{
+    POLY_ENTER((d_out && d_a && d_b) || n == 0);
+    return poly::mul_pointwise(d_out, d_a, d_b, n, st);
+}
+
+int bbgpu_kate_opening_device(const uint64_t* d_src, uint64_t* d_dest, size_t n, const uint64_t z[4], uint64_t f_of_z[4], void* hip_stream)
+{
+    POLY_ENTER(((d_src && d_dest) || n == 0) && z);
+    const host::Fr zz = load_fr(z);
+    if (f_of_z) {
+        host::Fr f;
+        int rc = poly::evaluate(d_src, n, zz, &f, g_ctx.poly_scratch, st);
+        if (rc) return rc;
+        memcpy(f_of_z, f.d, 32);
+    }
+    const uint64_t* src = d_src;
+    if (d_dest == d_src) { // the scan's last phase reads its input while writing: work from a copy
+        int rc = grow(&g_ctx.d_poly_tmp, &g_ctx.poly_tmp_cap, n * 32);
+        if (rc) return rc;
+        CHK(hipMemcpyAsync(g_ctx.d_poly_tmp, d_src, n * 32, hipMemcpyDeviceToDevice, st));
+        src = g_ctx.d_poly_tmp;
+    }
+    return poly::horner_suffix(src, d_dest, n, zz, false, g_ctx.poly_scratch, st, nullptr);
+}
+
+int bbgpu_lagrange_l1_fft_device(uint64_t* d_l_1, size_t n_src, size_t n_target, void* hip_stream)
+{
+    POLY_ENTER(d_l_1);
+    const int ls = log2_exact(n_src), lt = log2_exact(n_target);
+    if (ls < 1 || lt < ls || lt > 22) {
+        set_error("lagrange_l1_fft: domains must be powers of two, target >= source");
+        return BBGPU_ERR_SIZE;
+    }
+    int rc = grow(&g_ctx.d_poly_tmp, &g_ctx.poly_tmp_cap, n_target * 32);
+    if (rc) return rc;
+    return poly::lagrange_l1_fft(d_l_1, g_ctx.d_poly_tmp, ls, lt, g_ctx.poly_scratch, st);
+}
+
+int bbgpu_divide_by_pseudo_vanishing_device(uint64_t* d_coeffs, size_t n_src, size_t n_target, void* hip_stream)
+{
+    POLY_ENTER(d_coeffs);
+    const int ls = log2_exact(n_src), lt = log2_exact(n_target);
+    if (ls < 1 || lt < ls || lt > 22) {
+        set_error("divide_by_pseudo_vanishing: domains must be powers of two, target >= source");
+        return BBGPU_ERR_SIZE;
+    }
+    return poly::divide_by_pseudo_vanishing(d_coeffs, ls, lt, st);
+}
+
+int bbgpu_permutation_lagrange_base_device(uint64_t* d_out, const uint32_t* d_mapping, size_t n, void* hip_stream)
+{
+    POLY_ENTER(d_out && d_mapping);
+    const int lg = log2_exact(n);
+    if (lg < 1 || lg > 22) return BBGPU_ERR_SIZE;
+    int rc = grow(&g_ctx.d_poly_tmp, &g_ctx.poly_tmp_cap, n * 32);
+    if (rc) return rc;
+    rc = poly::powers(g_ctx.d_poly_tmp, n, host::fr_root_of_unity(lg), host::fr_one(), st);
+    if (rc) return rc;
+    return poly::sigma_from_mapping(d_out, d_mapping, g_ctx.d_poly_tmp, n, st);
 }
 
 /* ---- SRS ---- */

@@ -111,6 +111,54 @@ int bbgpu_msm_g1_wait(int ticket, uint64_t out[12]);
 /* out = sum of `count` normalised/Jacobian points (infinity flags honoured), normalised.  Host arithmetic. */
 int bbgpu_g1_sum(const uint64_t* points12, size_t count, uint64_t out[12]);
 
+/* ---- resident polynomial helpers -------------------------------------------------------------------
+ * The O(n) loops of the prover that sit between the transforms and the commitments, on device-resident vectors in the
+ * reference's memory format (n x 4 limbs, Montgomery; any representative below 2^256 in, canonical out).  All are
+ * asynchronous on `hip_stream` (NULL = the library's stream) except where a host value is returned. */
+/* polynomial_arithmetic::evaluate(coeffs, z, n) (polynomial_arithmetic.cpp:337-373): sum_i coeffs[i] z^i, canonical */
+int bbgpu_fr_evaluate_device(const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4], void* hip_stream);
+/* fr::batch_invert(coeffs, n) (fields/field.hpp:503-522), in place; every element must be non-zero */
+int bbgpu_fr_batch_invert_device(uint64_t* d_values, size_t n, void* hip_stream);
+/* running products (the six accumulator chains of prover.cpp:194-202 are the exclusive prefix form):
+ * out[i] = prod of in[j] over j < i (exclusive) or j <= i (inclusive); reverse != 0 scans from the top (j > i / j >= i) */
+int bbgpu_fr_product_scan_device(const uint64_t* d_in, uint64_t* d_out, size_t n, int reverse, int inclusive, void* hip_stream);
+/* polynomial_arithmetic::mul(a, b, r, domain) (:328-335) */
+int bbgpu_fr_mul_device(uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n, void* hip_stream);
+/* polynomial_arithmetic::compute_kate_opening_coefficients(src, dest, z, n) (:562-591): dest = (F(X) - F(z)) / (X - z),
+ * returns F(z) in f_of_z (may be NULL).  dest may alias src only if it IS src. */
+int bbgpu_kate_opening_device(const uint64_t* d_src, uint64_t* d_dest, size_t n, const uint64_t z[4], uint64_t f_of_z[4], void* hip_stream);
+/* polynomial_arithmetic::compute_lagrange_polynomial_fft(l_1, src_domain, target_domain) (:381-476): n_target values */
+int bbgpu_lagrange_l1_fft_device(uint64_t* d_l_1, size_t n_src, size_t n_target, void* hip_stream);
+/* polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial(coeffs, src_domain, target_domain) (:478-560), in place */
+int bbgpu_divide_by_pseudo_vanishing_device(uint64_t* d_coeffs, size_t n_src, size_t n_target, void* hip_stream);
+/* waffle::compute_permutation_lagrange_base_single(output, permutation, small_domain) (permutation.hpp:15-87) */
+int bbgpu_permutation_lagrange_base_device(uint64_t* d_out, const uint32_t* d_mapping, size_t n, void* hip_stream);
+
+/* ---- resident PLONK prover (BASELINE config 5) ------------------------------------------------------
+ * waffle::Prover for the standard arithmetic circuit with every polynomial resident in HBM.  The circuit description is
+ * the state StandardComposer::preprocess() hands the reference's Prover (standard_composer.cpp:163-220, prover.hpp:44-59,
+ * widgets/arithmetic_widget.hpp:45-49): per-gate wire VALUES, the three sigma permutation mappings (low bits: gate index,
+ * bits 30-31: 0 left / 1 right / 2 output wire) and the five selector VALUES, all of length n = 2^k.  The SRS is a registered
+ * / generated handle holding at least n points (monomials[i] = x^i G, reference_string.cpp:16-35). */
+typedef struct {
+    size_t n;
+    const uint64_t *w_l, *w_r, *w_o;                                   /* n x 4 limbs each */
+    const uint32_t *sigma_1_mapping, *sigma_2_mapping, *sigma_3_mapping; /* n each */
+    const uint64_t *q_m, *q_l, *q_r, *q_o, *q_c;                       /* n x 4 limbs each */
+} bbgpu_plonk_circuit;
+/* proof = waffle::plonk_proof (waffle_types.hpp:18-45) as filled for this circuit: W_L, W_R, W_O, Z_1, T_LO, T_MID, T_HI,
+ * PI_Z, PI_Z_OMEGA (affine x, y: 8 limbs each), then w_l_eval, w_r_eval, w_o_eval, sigma_1_eval, sigma_2_eval,
+ * z_1_shifted_eval, linear_eval (4 limbs each); Montgomery form, canonical -- byte-identical to the reference's proof */
+#define BBGPU_PLONK_PROOF_WORDS 100
+int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* circuit, int srs_handle); /* returns a prover handle >= 0 */
+int bbgpu_plonk_prover_set_witness(int prover, const uint64_t* w_l, const uint64_t* w_r, const uint64_t* w_o);
+int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF_WORDS]); /* Prover::construct_proof, prover.cpp:661-670 */
+int bbgpu_plonk_last_challenges(int prover, uint64_t out[20]); /* beta, gamma, alpha, z, nu (waffle_types.hpp:9-16) */
+int bbgpu_plonk_last_timing(int prover, double ms_out[4]);     /* construct_proof wall ms: total, in commitments, rest, first-use preparation */
+int bbgpu_plonk_prover_destroy(int prover);
+/* challenge.hpp:64-112 recomputed from a finished proof: gamma, beta, alpha, z (4 limbs each).  Host only, no GPU needed. */
+int bbgpu_plonk_challenges_from_proof(const uint64_t proof[BBGPU_PLONK_PROOF_WORDS], uint64_t out[16]);
+
 /* ---- instrumentation (bench.py) ---------------------------------------------------------------------------------
  * Device time in milliseconds of the kernels launched by the most recent bbgpu_*_device call on this thread, measured
  * with hipEvents on the stream the kernels ran on.  index: 0 = total, then per stage. */

@@ -11,6 +11,12 @@
 //   plonk_xxx transcript <path> <num_points>   write a synthetic SRS in the reference's transcript format (io.hpp:36-182)
 //   plonk_xxx prove <num_gates>                build the add/mul-chain circuit of test/benchmarks/bench_plonk.cpp:25-37 with
 //                                              fixed witnesses, prove, verify, print
+//   plonk_xxx trace <num_gates>                prove + also print the Fiat-Shamir challenges (debugging aid for restatements)
+//   plonk_xxx dump <num_gates> <path>          write the waffle::Prover INPUT state the composer produced (witness values,
+//                                              sigma mappings, selector values) as a flat binary file: the input of the native
+//                                              resident prover (bbgpu_plonk_*), so that it proves the very same circuit
+//   plonk_xxx verify <num_gates> < proof       rebuild the same circuit's Verifier and check a proof given in the `prove` text
+//                                              format on stdin (used to verify proofs made by the native GPU prover)
 #include <barretenberg/curves/bn254/fq.hpp>
 #include <barretenberg/curves/bn254/fr.hpp>
 #include <barretenberg/curves/bn254/g1.hpp>
@@ -19,6 +25,7 @@
 #include <barretenberg/waffle/proof_system/preprocess.hpp>
 #include <barretenberg/waffle/proof_system/prover/prover.hpp>
 #include <barretenberg/waffle/proof_system/verifier/verifier.hpp>
+#include <barretenberg/waffle/proof_system/widgets/arithmetic_widget.hpp>
 #include <barretenberg/waffle/stdlib/field/field.hpp>
 
 #include <arpa/inet.h>
@@ -82,20 +89,12 @@ void hex4(const char* name, const uint64_t* d)
     printf("%s %016lx%016lx%016lx%016lx\n", name, d[3], d[2], d[1], d[0]);
 }
 
-int prove(size_t num_gates)
+void build_circuit(waffle::StandardComposer& composer, size_t num_gates);
+
+int prove(size_t num_gates, bool trace)
 {
     waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
-    fr::field_t a0 = fr::to_montgomery_form({ { 0x1111111122222222ULL, 0x3333333344444444ULL, 0x5555555566666666ULL, 0x0777777788888888ULL } });
-    fr::field_t b0 = fr::to_montgomery_form({ { 0x9999aaaabbbbccccULL, 0xddddeeeeffff0000ULL, 0x1234123412341234ULL, 0x0abcdefabcdefabcULL } });
-    plonk::stdlib::field_t a(plonk::stdlib::witness_t(&composer, a0));
-    plonk::stdlib::field_t b(plonk::stdlib::witness_t(&composer, b0));
-    plonk::stdlib::field_t c(&composer);
-    for (size_t i = 0; i < (num_gates / 4) - 4; ++i) { // bench_plonk.cpp:30-36
-        c = a + b;
-        c = a * c;
-        a = b * b;
-        b = c * c;
-    }
+    build_circuit(composer, num_gates);
     waffle::Prover prover = composer.preprocess();
     waffle::Verifier verifier = waffle::preprocess(prover);
     auto t0 = std::chrono::steady_clock::now();
@@ -117,8 +116,92 @@ int prove(size_t num_gates)
                            "w_r_shifted_eval", "w_o_shifted_eval", "q_c_eval", "q_mimc_coefficient_eval" };
     for (int i = 0; i < 7; i++) hex4(en[i], ev[i]->data); // the standard arithmetic circuit fills these; the rest stay unset
     (void)en; (void)ev;
+    if (trace) {
+        hex4("beta", prover.challenges.beta.data);
+        hex4("gamma", prover.challenges.gamma.data);
+        hex4("alpha", prover.challenges.alpha.data);
+        hex4("z", prover.challenges.z.data);
+        hex4("nu", prover.challenges.nu.data);
+    }
     printf("verified %d\n", ok ? 1 : 0);
     fprintf(stderr, "construct_proof %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
+    return ok ? 0 : 2;
+}
+
+void build_circuit(waffle::StandardComposer& composer, size_t num_gates)
+{
+    fr::field_t a0 = fr::to_montgomery_form({ { 0x1111111122222222ULL, 0x3333333344444444ULL, 0x5555555566666666ULL, 0x0777777788888888ULL } });
+    fr::field_t b0 = fr::to_montgomery_form({ { 0x9999aaaabbbbccccULL, 0xddddeeeeffff0000ULL, 0x1234123412341234ULL, 0x0abcdefabcdefabcULL } });
+    plonk::stdlib::field_t a(plonk::stdlib::witness_t(&composer, a0));
+    plonk::stdlib::field_t b(plonk::stdlib::witness_t(&composer, b0));
+    plonk::stdlib::field_t c(&composer);
+    for (size_t i = 0; i < (num_gates / 4) - 4; ++i) { // bench_plonk.cpp:30-36
+        c = a + b;
+        c = a * c;
+        a = b * b;
+        b = c * c;
+    }
+}
+
+void wr(FILE* f, const void* p, size_t bytes) { if (fwrite(p, 1, bytes, f) != bytes) abort(); }
+
+int dump(size_t num_gates, const char* path)
+{
+    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
+    build_circuit(composer, num_gates);
+    waffle::Prover prover = composer.preprocess();
+    const waffle::ProverArithmeticWidget* w = dynamic_cast<const waffle::ProverArithmeticWidget*>(prover.widgets[0].get());
+    if (!w || prover.widgets.size() != 1) return 3;
+    FILE* f = fopen(path, "wb");
+    if (!f) return 1;
+    const uint64_t n = prover.n;
+    wr(f, "BBPLONK1", 8);
+    wr(f, &n, 8);
+    barretenberg::polynomial* wires[3] = { &prover.w_l, &prover.w_r, &prover.w_o };
+    for (auto* p : wires) wr(f, p->get_coefficients(), n * 32);
+    const std::vector<uint32_t>* maps[3] = { &prover.sigma_1_mapping, &prover.sigma_2_mapping, &prover.sigma_3_mapping };
+    for (auto* m : maps) wr(f, m->data(), n * 4);
+    const barretenberg::polynomial* sel[5] = { &w->q_m, &w->q_l, &w->q_r, &w->q_o, &w->q_c };
+    for (auto* p : sel) wr(f, const_cast<barretenberg::polynomial*>(p)->get_coefficients(), n * 32);
+    fclose(f);
+    printf("n %zu\n", (size_t)n);
+    return 0;
+}
+
+bool rd4(const char* want, uint64_t* d)
+{
+    char name[64], hex[80];
+    if (scanf("%63s %79s", name, hex) != 2 || strcmp(name, want) || strlen(hex) != 64) return false;
+    for (int l = 0; l < 4; l++) {
+        char buf[17];
+        memcpy(buf, hex + 16 * (3 - l), 16);
+        buf[16] = 0;
+        d[l] = strtoull(buf, nullptr, 16);
+    }
+    return true;
+}
+
+int verify(size_t num_gates)
+{
+    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
+    build_circuit(composer, num_gates);
+    waffle::Prover prover = composer.preprocess();
+    waffle::Verifier verifier = waffle::preprocess(prover);
+    waffle::plonk_proof proof;
+    g1::affine_element* pts[9] = { &proof.W_L, &proof.W_R, &proof.W_O, &proof.Z_1, &proof.T_LO, &proof.T_MID, &proof.T_HI, &proof.PI_Z, &proof.PI_Z_OMEGA };
+    const char* pn[9] = { "W_L", "W_R", "W_O", "Z_1", "T_LO", "T_MID", "T_HI", "PI_Z", "PI_Z_OMEGA" };
+    char nm[32];
+    size_t nn = 0;
+    if (scanf("n %zu", &nn) != 1 || nn != prover.n) return 4;
+    for (int i = 0; i < 9; i++) {
+        snprintf(nm, sizeof nm, "%s.x", pn[i]); if (!rd4(nm, pts[i]->x.data)) return 4;
+        snprintf(nm, sizeof nm, "%s.y", pn[i]); if (!rd4(nm, pts[i]->y.data)) return 4;
+    }
+    fr::field_t* ev[7] = { &proof.w_l_eval, &proof.w_r_eval, &proof.w_o_eval, &proof.sigma_1_eval, &proof.sigma_2_eval, &proof.z_1_shifted_eval, &proof.linear_eval };
+    const char* en[7] = { "w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval" };
+    for (int i = 0; i < 7; i++) if (!rd4(en[i], ev[i]->data)) return 4;
+    bool ok = verifier.verify_proof(proof);
+    printf("verified %d\n", ok ? 1 : 0);
     return ok ? 0 : 2;
 }
 } // namespace
@@ -126,7 +209,10 @@ int prove(size_t num_gates)
 int main(int argc, char** argv)
 {
     if (argc >= 4 && !strcmp(argv[1], "transcript")) return write_transcript(argv[2], (size_t)atol(argv[3]));
-    if (argc >= 3 && !strcmp(argv[1], "prove")) return prove((size_t)atol(argv[2]));
-    fprintf(stderr, "usage: %s transcript <path> <num_points> | prove <num_gates>\n", argv[0]);
+    if (argc >= 3 && !strcmp(argv[1], "prove")) return prove((size_t)atol(argv[2]), false);
+    if (argc >= 3 && !strcmp(argv[1], "trace")) return prove((size_t)atol(argv[2]), true);
+    if (argc >= 4 && !strcmp(argv[1], "dump")) return dump((size_t)atol(argv[2]), argv[3]);
+    if (argc >= 3 && !strcmp(argv[1], "verify")) return verify((size_t)atol(argv[2]));
+    fprintf(stderr, "usage: %s transcript <path> <num_points> | prove|trace|verify <num_gates> | dump <num_gates> <path>\n", argv[0]);
     return 64;
 }

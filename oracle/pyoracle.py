@@ -355,3 +355,144 @@ class Ref:
         r = aligned_empty((4,))
         self.lib.ref_evaluate(ptr(aligned_copy(coeffs)), ptr(aligned_copy(z)), C.c_size_t(coeffs.shape[0]), ptr(r))
         return np.array(r)
+
+    # ---- the O(n) helpers between the transforms ----
+    def batch_invert(self, v):
+        out = aligned_copy(v)
+        self.lib.ref_batch_invert(ptr(out), C.c_size_t(out.shape[0]))
+        return np.array(out)
+
+    def kate_opening(self, src, z):
+        """-> (dest, F(z)); dest is left coarse by the reference (polynomial_arithmetic.cpp:580-588)"""
+        src = aligned_copy(src)
+        dest = aligned_empty(src.shape)
+        f = aligned_empty((4,))
+        self.lib.ref_kate_opening(ptr(src), ptr(dest), ptr(aligned_copy(z)), C.c_size_t(src.shape[0]), ptr(f))
+        return np.array(dest), np.array(f)
+
+    def lagrange_l1_fft(self, n_src, n_target):
+        out = aligned_empty((n_target + 8, 4))
+        self.lib.ref_lagrange_l1_fft(ptr(out), C.c_size_t(n_src), C.c_size_t(n_target))
+        return np.array(out[:n_target])
+
+    def divide_by_pseudo_vanishing(self, coeffs, n_src, n_target):
+        out = aligned_copy(coeffs)
+        self.lib.ref_divide_by_pseudo_vanishing(ptr(out), C.c_size_t(n_src), C.c_size_t(n_target))
+        return np.array(out)
+
+    def pointwise_mul(self, a, b):
+        out = aligned_empty(a.shape)
+        self.lib.ref_pointwise_mul(ptr(aligned_copy(a)), ptr(aligned_copy(b)), ptr(out), C.c_size_t(a.shape[0]))
+        return np.array(out)
+
+    def lagrange_evaluations(self, z, n):
+        out = aligned_empty((3, 4))
+        self.lib.ref_lagrange_evaluations(ptr(aligned_copy(z)), C.c_size_t(n), ptr(out))
+        return np.array(out)
+
+
+class PolyOracle:
+    """Pure-Python (big integer) restatement of the reference's O(n) polynomial helpers, for small cases only.
+    Arrays in / out are (n, 4) uint64 Montgomery limbs like everywhere else; results are canonical.  Each method cites the
+    reference loop it follows; tests/test_oracle.py pins them against the reference build (Ref above)."""
+    R = FR_MODULUS
+    MONT = (1 << 256) % FR_MODULUS
+    MONT_INV = pow((1 << 256) % FR_MODULUS, -1, FR_MODULUS)
+    # fr.hpp:59-63: the 2^28-th root of unity, read out of its Montgomery form
+    ROOT28 = 0x1860EF942963F9E756452AC01EB203D8A22BF3742445FFD6636E735580D13D9C * pow(1 << 256, -1, FR_MODULUS) % FR_MODULUS
+    GENERATOR, K2 = 5, 7  # fr.hpp:65-79 (multiplicative_generator, alternate_multiplicative_generator)
+
+    @classmethod
+    def plain(cls, a):
+        a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+        return [to_int(row) * cls.MONT_INV % cls.R for row in a]
+
+    @classmethod
+    def mont(cls, values):
+        out = np.zeros((len(values), 4), dtype=np.uint64)
+        for i, v in enumerate(values):
+            out[i] = from_int(v % cls.R * cls.MONT % cls.R)
+        return out
+
+    @classmethod
+    def root(cls, log2n):  # field.hpp:487-494
+        return pow(cls.ROOT28, 1 << (28 - log2n), cls.R)
+
+    @classmethod
+    def evaluate(cls, coeffs, z):  # polynomial_arithmetic.cpp:337-373
+        zz, acc, zp = cls.plain(z)[0], 0, 1
+        for c in cls.plain(coeffs):
+            acc = (acc + c * zp) % cls.R
+            zp = zp * zz % cls.R
+        return cls.mont([acc])[0]
+
+    @classmethod
+    def batch_invert(cls, v):  # fields/field.hpp:503-522 (Montgomery's trick; same values as element-wise inversion)
+        return cls.mont([pow(x, -1, cls.R) for x in cls.plain(v)])
+
+    @classmethod
+    def product_scan(cls, v, reverse=False, inclusive=False):  # prover.cpp:194-202 is the exclusive prefix form
+        x = cls.plain(v)
+        if reverse:
+            x = x[::-1]
+        out, acc = [], 1
+        for a in x:
+            if inclusive:
+                acc = acc * a % cls.R
+                out.append(acc)
+            else:
+                out.append(acc)
+                acc = acc * a % cls.R
+        return cls.mont(out[::-1] if reverse else out)
+
+    @classmethod
+    def kate_opening(cls, src, z):  # polynomial_arithmetic.cpp:562-591, the reference's bottom-up recurrence
+        f, zz = cls.plain(src), cls.plain(z)[0]
+        fz = 0
+        for c in reversed(f):
+            fz = (fz * zz + c) % cls.R
+        divisor = pow(-zz % cls.R, -1, cls.R)
+        dest = [(f[0] - fz) * divisor % cls.R]
+        for i in range(1, len(f)):
+            dest.append((f[i] - dest[i - 1]) * divisor % cls.R)
+        return cls.mont(dest), cls.mont([fz])[0]
+
+    @classmethod
+    def lagrange_l1_fft(cls, n_src, n_target):  # polynomial_arithmetic.cpp:381-476
+        ls, lt = n_src.bit_length() - 1, n_target.bit_length() - 1
+        k = n_target // n_src
+        wt, gn, wk = cls.root(lt), pow(cls.GENERATOR, n_src, cls.R), cls.root(lt - ls)
+        numer = [(gn * pow(wk, j, cls.R) - 1) * pow(n_src, -1, cls.R) % cls.R for j in range(k)]
+        out, x = [], cls.GENERATOR
+        for i in range(n_target):
+            out.append(pow(x - 1, -1, cls.R) * numer[i % k] % cls.R)
+            x = x * wt % cls.R
+        return cls.mont(out)
+
+    @classmethod
+    def divide_by_pseudo_vanishing(cls, coeffs, n_src, n_target):  # polynomial_arithmetic.cpp:478-560
+        ls, lt = n_src.bit_length() - 1, n_target.bit_length() - 1
+        k = n_target // n_src
+        wt, gn, wk = cls.root(lt), pow(cls.GENERATOR, n_src, cls.R), cls.root(lt - ls)
+        inv = [pow(gn * pow(wk, j, cls.R) - 1, -1, cls.R) for j in range(k)]
+        last = pow(cls.root(ls), -1, cls.R)  # w^(n-1)
+        out, x = [], cls.GENERATOR
+        for i, c in enumerate(cls.plain(coeffs)):
+            out.append(c * inv[i % k] % cls.R * ((x - last) % cls.R) % cls.R)
+            x = x * wt % cls.R
+        return cls.mont(out)
+
+    @classmethod
+    def permutation_lagrange_base(cls, mapping, n):  # waffle/proof_system/permutation.hpp:15-87
+        w = cls.root(n.bit_length() - 1)
+        out = []
+        for m in mapping:
+            m = int(m)
+            v = pow(w, m & ((1 << 29) - 1), cls.R)
+            t = (m >> 30) & 3
+            out.append(v * (cls.K2 if t == 2 else cls.GENERATOR if t == 1 else 1) % cls.R)
+        return cls.mont(out)
+
+    @classmethod
+    def pointwise_mul(cls, a, b):  # polynomial_arithmetic.cpp:328-335
+        return cls.mont([x * y % cls.R for x, y in zip(cls.plain(a), cls.plain(b))])

@@ -203,5 +203,37 @@ void ref_evaluate(const uint64_t* coeffs, const uint64_t* z, size_t n, uint64_t*
     fr::field_t o = polynomial_arithmetic::evaluate((const fr::field_t*)coeffs, zz, n);
     st(r, o.data);
 }
+
+// ---- the O(n) helpers between the transforms; buffers 32-byte aligned ---------------------------------
+void ref_batch_invert(uint64_t* coeffs, size_t n) { fr::batch_invert((fr::field_t*)coeffs, n); }
+
+// outputs are left coarse ([0, 2r)) by the reference on purpose (polynomial_arithmetic.cpp:580-588); f receives F(z)
+void ref_kate_opening(const uint64_t* src, uint64_t* dest, const uint64_t* z, size_t n, uint64_t* f)
+{
+    fr::field_t zz = ldr(z);
+    fr::field_t o = polynomial_arithmetic::compute_kate_opening_coefficients((const fr::field_t*)src, (fr::field_t*)dest, zz, n);
+    st(f, o.data);
+}
+void ref_lagrange_l1_fft(uint64_t* l_1, size_t n_src, size_t n_target)
+{
+    polynomial_arithmetic::compute_lagrange_polynomial_fft((fr::field_t*)l_1, get_domain(n_src), get_domain(n_target));
+}
+void ref_divide_by_pseudo_vanishing(uint64_t* coeffs, size_t n_src, size_t n_target)
+{
+    polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial((fr::field_t*)coeffs, get_domain(n_src), get_domain(n_target));
+}
+void ref_pointwise_mul(const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n)
+{
+    polynomial_arithmetic::mul((const fr::field_t*)a, (const fr::field_t*)b, (fr::field_t*)r, get_domain(n));
+}
+// {Z_H*(z), L_1(z), L_{n-1}(z)} (polynomial_arithmetic.cpp:594-626)
+void ref_lagrange_evaluations(const uint64_t* z, size_t n, uint64_t* out12)
+{
+    fr::field_t zz = ldr(z);
+    polynomial_arithmetic::lagrange_evaluations e = polynomial_arithmetic::get_lagrange_evaluations(zz, get_domain(n));
+    st(out12, e.vanishing_poly.data);
+    st(out12 + 4, e.l_1.data);
+    st(out12 + 8, e.l_n_minus_1.data);
+}
 }
 #pragma GCC visibility pop

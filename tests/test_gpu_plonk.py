@@ -1,0 +1,202 @@
+"""GPU parity tests (-m gpu) of the resident polynomial helpers (poly.hip) and of the resident PLONK
+prover (plonk.hip, SURVEY 8f #2 / BASELINE config 5), through the C ABI.  Bit-exact bar.
+
+Checkers: oracle.pyoracle.PolyOracle (big-integer restatement, pinned by tests/golden/poly_ops.json = outputs of the
+reference itself), the fixtures directly, size-independent properties at full size, and for the prover the reference's own
+golden proofs (tests/golden/plonk_proofs.json) plus, when the reference build travelled to the box, its Verifier."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FR_MODULUS, PolyOracle as P, to_int
+from tests.util import noncanonical
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from barretenberg_amd import BbGpu
+    g = BbGpu(device=0)
+    yield g
+    g.shutdown()
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host(t):
+    import torch
+    torch.cuda.synchronize()  # the helpers are asynchronous on the library's own (non-blocking) stream
+    return t.cpu().numpy().view(np.uint64)
+
+
+def hx(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return ["%064x" % to_int(r) for r in a]
+
+
+# ------------------------------------------------------------------ helpers vs the reference's fixtures ---------------
+def test_poly_helpers_match_reference_fixtures(gpu, torch, oracle, golden):
+    for case in golden("poly_ops.json")["cases"]:
+        n, seed = case["n"], case["seed"]
+        v, z, w = oracle.random_scalars(seed, n), oracle.random_scalars(seed + 1, 1)[0], oracle.random_scalars(seed + 2, n)
+        dv, dw = dev(torch, v), dev(torch, w)
+        assert hx(gpu.evaluate_device(dv.data_ptr(), n, z))[0] == case["evaluate"]
+        d = dv.clone()
+        gpu.batch_invert_device(d.data_ptr(), n)
+        assert hx(host(d)) == case["batch_invert"]
+        dest = torch.zeros_like(dv)
+        f = gpu.compute_kate_opening_coefficients_device(dv.data_ptr(), dest.data_ptr(), n, z)
+        assert hx(host(dest)) == case["kate_dest"] and hx(f)[0] == case["kate_f"]
+        out = torch.zeros_like(dv)
+        gpu.mul_device(out.data_ptr(), dv.data_ptr(), dw.data_ptr(), n)
+        assert hx(host(out)) == case["pointwise_mul"]
+        l1 = torch.zeros((2 * n, 4), dtype=torch.int64, device="cuda")
+        gpu.compute_lagrange_polynomial_fft_device(l1.data_ptr(), n, 2 * n)
+        assert hx(host(l1)) == case["lagrange_l1_fft_2n"]
+        for k, off, key in ((2, 3, "divide_vanishing_2n"), (4, 4, "divide_vanishing_4n")):
+            c = dev(torch, oracle.random_scalars(seed + off, k * n))
+            gpu.divide_by_pseudo_vanishing_polynomial_device(c.data_ptr(), n, k * n)
+            assert hx(host(c)) == case[key]
+
+
+# ------------------------------------------------------------------ helpers vs the big-integer oracle, ragged sizes -----
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 255, 256, 257, 2047, 2048, 2049, 5000])
+def test_scans_and_evaluate_vs_oracle(gpu, torch, oracle, n):
+    """sizes around the run (8), workgroup (2048) and two-workgroup boundaries; inputs partly non-canonical ([r, 2r))"""
+    v = noncanonical(oracle.random_scalars(0x5CA9 + n, n), FR_MODULUS)
+    z = oracle.random_scalars(0x5CAA + n, 1)[0]
+    dv = dev(torch, v)
+    assert np.array_equal(gpu.evaluate_device(dv.data_ptr(), n, z), P.evaluate(v, z))
+    out = torch.zeros_like(dv)
+    for reverse in (False, True):
+        for inclusive in (False, True):
+            gpu.product_scan_device(dv.data_ptr(), out.data_ptr(), n, reverse, inclusive)
+            assert np.array_equal(host(out), P.product_scan(v, reverse, inclusive)), (n, reverse, inclusive)
+    f = gpu.compute_kate_opening_coefficients_device(dv.data_ptr(), out.data_ptr(), n, z)
+    want, wf = P.kate_opening(v, z)
+    assert np.array_equal(host(out), want) and np.array_equal(f, wf)
+    # in place
+    d2 = dv.clone()
+    gpu.compute_kate_opening_coefficients_device(d2.data_ptr(), d2.data_ptr(), n, z)
+    assert np.array_equal(host(d2), want)
+    d3 = dv.clone()
+    gpu.batch_invert_device(d3.data_ptr(), n)
+    assert np.array_equal(host(d3), P.batch_invert(v))
+
+
+@pytest.mark.parametrize("log2n", [2, 5, 10])
+def test_domain_helpers_vs_oracle(gpu, torch, oracle, log2n):
+    n = 1 << log2n
+    for k in (1, 2, 4):
+        l1 = torch.zeros((k * n, 4), dtype=torch.int64, device="cuda")
+        gpu.compute_lagrange_polynomial_fft_device(l1.data_ptr(), n, k * n)
+        assert np.array_equal(host(l1), P.lagrange_l1_fft(n, k * n)), (n, k)
+        c = oracle.random_scalars(0xD1F + n + k, k * n)
+        dc = dev(torch, c)
+        gpu.divide_by_pseudo_vanishing_polynomial_device(dc.data_ptr(), n, k * n)
+        assert np.array_equal(host(dc), P.divide_by_pseudo_vanishing(c, n, k * n)), (n, k)
+    rng = np.random.default_rng(n)
+    mapping = (rng.integers(0, n, size=n, dtype=np.uint32) + (rng.integers(0, 3, size=n, dtype=np.uint32) << np.uint32(30))).astype(np.uint32)
+    dm = torch.from_numpy(mapping.view(np.int32)).cuda()
+    out = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    gpu.compute_permutation_lagrange_base_single_device(out.data_ptr(), dm.data_ptr(), n)
+    assert np.array_equal(host(out), P.permutation_lagrange_base(mapping, n))
+
+
+# ------------------------------------------------------------------ size-independent properties at BASELINE size ---------
+def test_helpers_properties_2_20(gpu, torch, oracle):
+    """n = 2^20: a^-1 * a = 1 everywhere; (X - z) W(X) + F(z) = F(X) checked at a random point through evaluate;
+    inclusive prefix product's last element = exclusive suffix product's first * a_0; evaluate is linear"""
+    n = 1 << 20
+    v = oracle.random_scalars(0xB16, n)
+    z, x = oracle.random_scalars(0xB17, 2)
+    dv = dev(torch, v)
+    inv = dv.clone()
+    gpu.batch_invert_device(inv.data_ptr(), n)
+    prod = torch.zeros_like(dv)
+    gpu.mul_device(prod.data_ptr(), dv.data_ptr(), inv.data_ptr(), n)
+    one = torch.from_numpy(P.mont([1]).view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    assert bool((prod == one).all())
+    w = torch.zeros_like(dv)
+    fz = gpu.compute_kate_opening_coefficients_device(dv.data_ptr(), w.data_ptr(), n, z)
+    fx = P.plain(gpu.evaluate_device(dv.data_ptr(), n, x))[0]
+    wx = P.plain(gpu.evaluate_device(w.data_ptr(), n, x))[0]
+    zp, xp, fzp = P.plain(z)[0], P.plain(x)[0], P.plain(fz)[0]
+    assert ((xp - zp) * wx + fzp) % FR_MODULUS == fx
+    assert np.array_equal(fz, gpu.evaluate_device(dv.data_ptr(), n, z))
+    pre, suf = torch.zeros_like(dv), torch.zeros_like(dv)
+    gpu.product_scan_device(dv.data_ptr(), pre.data_ptr(), n, False, True)
+    gpu.product_scan_device(dv.data_ptr(), suf.data_ptr(), n, True, False)
+    total = P.plain(host(pre[n - 1:n]))[0]
+    assert total == P.plain(host(suf[0:1]))[0] * P.plain(v[0:1])[0] % FR_MODULUS
+    # chunk-wise check of the whole-vector product against the big-integer oracle on a sub-range
+    m = 3000
+    assert P.plain(host(pre[m - 1:m]))[0] == P.plain(P.product_scan(v[:m], False, True)[m - 1:m])[0]
+
+
+# ------------------------------------------------------------------ the resident prover ----------------------------------
+SECRET_RAW = 0x0123456789ABCDEF_0F1E2D3C4B5A6978_FEDCBA9876543210_0123456789ABCDEF  # oracle/plonk_driver.cpp secret(), limbs 3..0
+
+
+@pytest.fixture(scope="module")
+def srs65536(gpu):
+    x_mont = P.mont([SECRET_RAW % FR_MODULUS])[0]
+    return gpu.srs_generate(x_mont, 65536)
+
+
+@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536])
+def test_resident_prover_proof_is_byte_identical(gpu, srs65536, golden, gates):
+    """BASELINE config 5, natively: the bench_plonk.cpp add/mul-chain circuit built by the StandardComposer mirror (its state is
+    pinned against the reference composer in tests/test_plonk_host.py), proved by bbgpu_plonk_construct_proof with all
+    polynomials resident, against the proof the reference's all-CPU prover made for the same circuit, witnesses and SRS."""
+    from barretenberg_amd.plonk import Prover, bench_circuit, proof_lines
+    tr = golden("plonk_trace.json")
+    state = bench_circuit(gates, int(tr["witness_a0"], 16), int(tr["witness_b0"], 16)).preprocess()
+    prover = Prover(gpu, state, srs65536)
+    try:
+        want = golden("plonk_proofs.json")["proofs"][str(gates)]
+        proof = prover.construct_proof()
+        got = proof_lines(state["n"], proof)
+        ch = prover.challenges()
+        for name in ("gamma", "beta", "alpha", "z", "nu"):
+            assert hx(ch[name])[0] == tr["challenges"][str(gates)][name], name
+        assert got == want[:26]
+        # proving again (cached circuit state, same witness) and after re-uploading the witness gives the same bytes
+        assert np.array_equal(prover.construct_proof(), proof)
+        prover.set_witness(state["w_l"], state["w_r"], state["w_o"])
+        assert np.array_equal(prover.construct_proof(), proof)
+        # the reference's own Verifier accepts it (when the reference build travelled with the repo)
+        exe = os.path.join(ROOT, "oracle", "_ref", "plonk_cpu")
+        if os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "transcript.dat")):
+            r = subprocess.run([exe, "verify", str(gates)], input="\n".join(got) + "\n", cwd=ROOT, capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, OMP_NUM_THREADS="16"))
+            assert r.returncode == 0 and r.stdout.strip() == "verified 1", (r.stdout, r.stderr[-500:])
+    finally:
+        prover.destroy()
+
+
+def test_resident_prover_rejects_bad_input(gpu, srs65536):
+    from barretenberg_amd import BbGpuError
+    from barretenberg_amd.plonk import Prover, bench_circuit
+    state = bench_circuit(32, 3, 5).preprocess()
+    bad = dict(state, n=24)
+    for k in bad:
+        if k != "n":
+            bad[k] = bad[k][:24]
+    with pytest.raises(BbGpuError):
+        Prover(gpu, bad, srs65536)
+    with pytest.raises(BbGpuError):
+        Prover(gpu, state, 12345)

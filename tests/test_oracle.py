@@ -274,3 +274,54 @@ def test_fft_roundtrips(oracle):
 def test_ntt_kinds_complete():
     assert set(NTT_KINDS) == {"fft", "ifft", "coset_fft", "coset_ifft", "fft_with_constant", "ifft_with_constant",
                               "coset_fft_with_constant"}
+
+
+# ---- the O(n) polynomial helpers: PolyOracle pinned by fixtures made by the reference itself -----------------
+def _hx(a, canonical=False):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return ["%064x" % (to_int(r) % FR_MODULUS if canonical else to_int(r)) for r in a]
+
+
+def test_poly_oracle_matches_reference_fixtures(oracle, golden):
+    from oracle.pyoracle import PolyOracle as P
+    for case in golden("poly_ops.json")["cases"]:
+        n, seed = case["n"], case["seed"]
+        v, z, w = oracle.random_scalars(seed, n), oracle.random_scalars(seed + 1, 1)[0], oracle.random_scalars(seed + 2, n)
+        assert _hx(z)[0] == case["z"]
+        assert _hx(P.evaluate(v, z))[0] == case["evaluate"]
+        assert _hx(oracle.evaluate(v, z))[0] == case["evaluate"]
+        assert _hx(P.batch_invert(v)) == case["batch_invert"]
+        dest, f = P.kate_opening(v, z)
+        assert _hx(dest) == case["kate_dest"] and _hx(f)[0] == case["kate_f"]
+        assert _hx(P.pointwise_mul(v, w)) == case["pointwise_mul"]
+        assert _hx(P.lagrange_l1_fft(n, 2 * n)) == case["lagrange_l1_fft_2n"]
+        c2, c4 = oracle.random_scalars(seed + 3, 2 * n), oracle.random_scalars(seed + 4, 4 * n)
+        assert _hx(P.divide_by_pseudo_vanishing(c2, n, 2 * n)) == case["divide_vanishing_2n"]
+        assert _hx(P.divide_by_pseudo_vanishing(c4, n, 4 * n)) == case["divide_vanishing_4n"]
+
+
+def test_poly_oracle_internal_consistency(oracle):
+    """properties the restatement must have whatever the reference does: inverse * value = 1, (X - z) W(X) + F(z) = F(X),
+    the exclusive prefix product is the reference's accumulator chain (prover.cpp:194-202), sigma of the identity mapping"""
+    from oracle.pyoracle import PolyOracle as P
+    n = 32
+    v, z = oracle.random_scalars(77, n), oracle.random_scalars(78, 1)[0]
+    one = P.mont([1])[0]
+    inv = P.batch_invert(v)
+    assert all(np.array_equal(r, one) for r in P.pointwise_mul(v, inv))
+    dest, f = P.kate_opening(v, z)
+    fp, wp, zp, fz = P.plain(v), P.plain(dest), P.plain(z)[0], P.plain(f)[0]
+    assert wp[n - 1] == 0
+    for i in range(n):
+        lhs = ((wp[i - 1] if i else 0) - zp * wp[i] + (fz if i == 0 else 0)) % FR_MODULUS
+        assert lhs == fp[i]
+    ex = P.plain(P.product_scan(v))
+    chain = [1]
+    for a in P.plain(v)[:-1]:
+        chain.append(chain[-1] * a % FR_MODULUS)
+    assert ex == chain
+    assert P.plain(P.product_scan(v, reverse=True, inclusive=True))[0] == chain[-1] * P.plain(v)[-1] % FR_MODULUS
+    ident = np.arange(n, dtype=np.uint32)
+    w = P.root(5)
+    assert P.plain(P.permutation_lagrange_base(ident, n)) == [pow(w, i, FR_MODULUS) for i in range(n)]
+    assert P.plain(P.permutation_lagrange_base(ident + np.uint32(1 << 31), n)) == [7 * pow(w, i, FR_MODULUS) % FR_MODULUS for i in range(n)]

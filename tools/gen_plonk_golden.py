@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Fixtures for the resident PLONK prover, produced by the reference itself (oracle/_ref/plonk_cpu = the reference's
+unmodified composer / prover / verifier compiled in place by oracle/Makefile; driver oracle/plonk_driver.cpp):
+
+  tests/golden/plonk_trace.json    Fiat-Shamir challenges (beta, gamma, alpha, z, nu) of the golden proofs, and SHA-256
+                                   digests of the waffle::Prover input state (`plonk_cpu dump`) per circuit size, plus the
+                                   complete input state of the 32-gate circuit
+Run in the build container (needs /root/reference at oracle build time):  python tools/gen_plonk_golden.py
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+EXE = os.path.join(ROOT, "oracle", "_ref", "plonk_cpu")
+FIELDS64 = ("w_l", "w_r", "w_o")
+MAPS = ("sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping")
+SELECTORS = ("q_m", "q_l", "q_r", "q_o", "q_c")
+
+
+def load_dump(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"BBPLONK1"
+    n = int.from_bytes(b[8:16], "little")
+    o, st = 16, {"n": n}
+    for k in FIELDS64:
+        st[k] = np.frombuffer(b, dtype=np.uint64, count=4 * n, offset=o).reshape(n, 4); o += 32 * n
+    for k in MAPS:
+        st[k] = np.frombuffer(b, dtype=np.uint32, count=n, offset=o); o += 4 * n
+    for k in SELECTORS:
+        st[k] = np.frombuffer(b, dtype=np.uint64, count=4 * n, offset=o).reshape(n, 4); o += 32 * n
+    return st
+
+
+def main():
+    out = {"source": "oracle/_ref/plonk_cpu {trace,dump} <gates> (the reference's own composer and prover; see tools/gen_plonk_golden.py)",
+           "witness_a0": "0777777788888888555555556666666633333333444444441111111122222222",
+           "witness_b0": "0abcdefabcdefabc1234123412341234ddddeeeeffff00009999aaaabbbbcccc",
+           "challenges": {}, "input_digests": {}}
+    for gates in (32, 1024, 16384, 65536):
+        r = subprocess.run([EXE, "trace", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True)
+        lines = r.stdout.strip().split("\n")
+        ch = {ln.split()[0]: ln.split()[1] for ln in lines if ln.split()[0] in ("beta", "gamma", "alpha", "z", "nu")}
+        out["challenges"][str(gates)] = ch
+        path = "/tmp/plonk_dump_%d.bin" % gates
+        subprocess.run([EXE, "dump", str(gates), path], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+        st = load_dump(path)
+        out["input_digests"][str(gates)] = {k: hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() for k in FIELDS64 + MAPS + SELECTORS}
+        out["input_digests"][str(gates)]["n"] = st["n"]
+        if gates == 32:
+            out["input_state_32"] = {k: [["%016x" % int(v) for v in row] for row in st[k]] for k in FIELDS64 + SELECTORS}
+            out["input_state_32"].update({k: [int(v) for v in st[k]] for k in MAPS})
+        os.remove(path)
+    with open(os.path.join(ROOT, "tests", "golden", "plonk_trace.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+    print("wrote tests/golden/plonk_trace.json")
+
+
+if __name__ == "__main__":
+    main()
