@@ -227,7 +227,7 @@ class BbGpu:
         return out
 
     def msm_device_async(self, handle, d_scalars_ptr, n, offset=0, window_begin=0, window_end=None, stream=None):
-        """enqueue; returns a ticket for msm_wait().  At most two MSMs in flight."""
+        """enqueue; returns a ticket for msm_wait().  At most four MSMs in flight."""
         if window_end is None:
             window_end = self.srs_num_windows(handle, n)
         return self._chk(self.lib.bbgpu_msm_g1_device_async(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -40,7 +41,8 @@ struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<SrsEntry> srs;
-    MsmSlot slot[2];
+    static constexpr int NSLOT = 4; // asynchronous MSMs in flight (each with its own workspace and stream)
+    MsmSlot slot[NSLOT];
     int next_slot = 0;
     uint64_t* d_stage = nullptr; // scalars / coefficients staging
     size_t stage_cap = 0;
@@ -228,8 +230,7 @@ void bbgpu_shutdown(void)
         if (e.live && e.d_tab) (void)hipFree(e.d_tab);
     }
     g_ctx.srs.clear();
-    g_ctx.slot[0].release();
-    g_ctx.slot[1].release();
+    for (auto& sl : g_ctx.slot) sl.release();
     if (g_ctx.d_stage) (void)hipFree(g_ctx.d_stage);
     if (g_ctx.d_stage2) (void)hipFree(g_ctx.d_stage2);
     g_ctx.d_stage2 = nullptr;
@@ -553,10 +554,15 @@ int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_s
         set_error("MSM range [%zu, %zu) outside the registered table of %zu points", offset, offset + n, e.n);
         return BBGPU_ERR_ARG;
     }
-    int t = g_ctx.next_slot;
-    if (g_ctx.slot[t].pending) t ^= 1;
-    if (g_ctx.slot[t].pending) {
-        set_error("both MSM slots are in flight: call bbgpu_msm_g1_wait first");
+    // slots 0 and 1 alternate (the two-deep pipeline of consecutive large MSMs: measured 1.50 ms/step against 1.72 when four
+    // streams rotate -- more streams than hardware queues delay the next MSM's sort behind the previous one's tail);
+    // slots 2 and 3 only take the overflow when both are busy (a prover round's three side-by-side commitments)
+    int t = -1;
+    const int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1, 2, 3 };
+    for (int k = 0; k < Context::NSLOT; k++)
+        if (!g_ctx.slot[order[k]].pending) { t = order[k]; break; }
+    if (t < 0) {
+        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
         return BBGPU_ERR_STATE;
     }
     MsmSlot& S = g_ctx.slot[t];
@@ -565,14 +571,14 @@ int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_s
     rc = issue_on_entry(S, e, offset, d_scalars, n, window_begin, window_end, st);
     if (rc == BBGPU_ERR_ARG) set_error("bad window range [%d, %d)", window_begin, window_end);
     if (rc) return rc;
-    g_ctx.next_slot = t ^ 1;
+    if (t < 2) g_ctx.next_slot = t ^ 1;
     return t;
 }
 
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12])
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (ticket < 0 || ticket > 1 || !g_ctx.slot[ticket].pending) {
+    if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending) {
         set_error("no MSM in flight for ticket %d", ticket);
         return BBGPU_ERR_ARG;
     }

@@ -72,6 +72,29 @@ __device__ __forceinline__ void ld32(const uint32_t* p, uint32_t (&w)[32])
     }
 }
 
+// ---- digit windows ---------------------------------------------------------------------------------------------------
+struct WinLayout {
+    uint16_t off[66]; // off[w] = first bit of window w; off[W] = end
+};
+static WinLayout make_layout(int c, bool balanced)
+{
+    WinLayout LO{};
+    const int W = msm_num_windows(c);
+    if (!balanced) {
+        for (int w = 0; w <= W; w++) LO.off[w] = (uint16_t)(c * w);
+        return LO;
+    }
+    // W windows of base or base + 1 bits covering exactly the 254 bits of a canonical scalar, wider ones at the bottom;
+    // base = floor(254 / W) <= c - 1, so the (unsigned) top window value <= 2^(c-1) still indexes a bucket
+    const int base = SCALAR_BITS / W, rem = SCALAR_BITS - base * W;
+    int bit = 0;
+    for (int w = 0; w < W; w++) {
+        LO.off[w] = (uint16_t)bit;
+        bit += base + (w < rem ? 1 : 0);
+    }
+    LO.off[W] = (uint16_t)bit;
+    return LO;
+}
 // ---------------------------------------------------------------------------------------------------------------------
 // SRS: reference endo table (2n x 64 B, Montgomery 2^256) -> resident base points (n x 64 B, Montgomery 2^261, canonical)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -112,10 +135,11 @@ __global__ void srs_export_kernel(const uint32_t* __restrict__ srs, uint32_t* __
     for (int k = 0; k < 8; k++) dst[24 + k] = o[k];
 }
 
-// ---- pre-shifted window tables: tab[w * n + i] = 2^(c w) * P_i, affine canonical Montgomery-261 -----------------------
+// ---- pre-shifted window tables: tab[w * n + i] = 2^off[w] * P_i, affine canonical Montgomery-261 ----------------------
 // (the reference's generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129, built on the device).
-// One lane per base point: c doublings per window, one inversion per stored point.  Once per SRS.
-__global__ void __launch_bounds__(MSM_THREADS) srs_table_kernel(const uint32_t* __restrict__ srs, uint32_t* __restrict__ tab, uint32_t n, uint32_t c,
+// One lane per base point: off[w] - off[w-1] doublings per window, one inversion per stored point.  Once per SRS.
+
+__global__ void __launch_bounds__(MSM_THREADS) srs_table_kernel(const uint32_t* __restrict__ srs, uint32_t* __restrict__ tab, uint32_t n, WinLayout LO,
                                                               uint32_t num_windows)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,7 +156,7 @@ __global__ void __launch_bounds__(MSM_THREADS) srs_table_kernel(const uint32_t* 
     Xyzz acc;
     from_affine(acc, p);
     for (uint32_t w = 1; w < num_windows; w++) {
-        for (uint32_t k = 0; k < c; k++) {
+        for (uint32_t k = LO.off[w - 1]; k < LO.off[w]; k++) {
             Xyzz t;
             dbl(t, acc);
             acc = t;
@@ -224,10 +248,16 @@ __global__ void srs_gen_points_kernel(const uint32_t* __restrict__ tab, Limbs9 x
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K0: scalars (Montgomery 2^256, any representative) -> signed digits, window-major int16
-//     d in [-2^(c-1), 2^(c-1)),  k = sum_w d_w 2^(c w);  replaces a5 + a6 + a7 (from_montgomery, endo split, wNAF)
+//     window w covers bits [off[w], off[w+1]) of the canonical scalar; d_w in [-2^(s_w - 1), 2^(s_w - 1)) with a carry into
+//     the next window, the top window keeps its value (no carry out);  k = sum_w d_w 2^off[w].
+//     Replaces a5 + a6 + a7 (from_montgomery, endo split, wNAF).
+//     Two layouts (make_layout): uniform windows of c bits when every window owns a bucket set (the host then combines the
+//     windows by c doublings each), and BALANCED windows of c or c - 1 bits when pre-shifted tables feed one shared bucket set:
+//     254 = 21 * 12 + 2 would leave a 2-bit top window whose n entries all land in 3 buckets (measured at n = 2^16: one
+//     workgroup of the sort and the heavy-bucket merge became the critical path, 130 us of a 570 us MSM).
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
-                                                               uint32_t n, uint32_t c, uint32_t num_windows)
+                                                               uint32_t n, WinLayout LO, uint32_t num_windows)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -237,18 +267,18 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(const uint32_t*
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = w[j];
     k[8] = 0;
-    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
     uint32_t carry = 0;
     for (uint32_t win = 0; win < num_windows; win++) {
-        const uint32_t bit = win * c, j = bit >> 5, s = bit & 31;
+        const uint32_t bit = LO.off[win], sz = LO.off[win + 1] - bit, j = bit >> 5, s = bit & 31;
+        const uint32_t half = 1u << (sz - 1), mask = (1u << sz) - 1;
         uint32_t v = 0;
         if (j < 8) {
             v = k[j] >> s;
-            if (s + c > 32) v |= k[j + 1] << (32 - s);
+            if (s + sz > 32) v |= k[j + 1] << (32 - s);
         }
         v = (v & mask) + carry;
-        carry = v >= half ? 1u : 0u;
-        const int32_t d = (int32_t)v - (int32_t)(carry << c);
+        carry = (win + 1 < num_windows && v >= half) ? 1u : 0u;
+        const int32_t d = (int32_t)v - (int32_t)(carry << sz);
         digits[(size_t)win * n + i] = (int16_t)d;
     }
 }
@@ -482,35 +512,59 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint3
 }
 
 // K4m: bucket b = sum of its partials, slots b + floor(s/ch) .. b + floor((e-1)/ch); written canonical for K5.
-// Buckets cut into more than MERGE_LIGHT partials (skewed digit distributions, the short top window) are queued and
-// summed by a whole workgroup each (K4h), so no lane ever walks a long list.
+// 2^logG lanes share a bucket: lane j adds partials j, j + G, ... and the group is combined by a shuffle tree, so the dependent
+// chain is ~ceil(count / G) + logG additions instead of `count` (one XYZZ addition is ~8 us of issue time for a lone wave:
+// a 2^16-point MSM against window tables cuts every bucket into ~90 partials).  Buckets cut into more than MERGE_LIGHT
+// partials (skewed digit distributions) are queued and summed by a whole workgroup each (K4h).
+__device__ __forceinline__ Xyzz shfl_down_xyzz(const Xyzz& p, uint32_t off)
+{
+    Xyzz r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        r.x.d[i] = __shfl_down(p.x.d[i], off);
+        r.y.d[i] = __shfl_down(p.y.d[i], off);
+        r.zz.d[i] = __shfl_down(p.zz.d[i], off);
+        r.zzz.d[i] = __shfl_down(p.zzz.d[i], off);
+    }
+    return r;
+}
 __global__ void __launch_bounds__(MSM_THREADS) msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                               uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
-                                                              uint32_t ch, uint32_t MERGE_LIGHT)
+                                                              uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logG)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= total_buckets) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t G = 1u << logG, b = t >> logG, j = t & (G - 1);
+    if (b >= total_buckets) return; // whole groups leave together (groups are aligned inside a wave)
     const uint32_t s = gstart[b], e = gstart[b + 1];
     Xyzz acc;
     set_infinity(acc);
     if (e > s) {
         const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
         if (t1 - t0 >= MERGE_LIGHT) { // heavy[0] = count, heavy[1..] = bucket ids
-            heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
+            if (j == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
             return;
         }
-        load_raw(acc, partials + (size_t)(b + t0) * RAW_WORDS);
-        for (uint32_t t = t0 + 1; t <= t1; t++) {
+        for (uint32_t k = t0 + j; k <= t1; k += G) {
             Xyzz q, r;
-            load_raw(q, partials + (size_t)(b + t) * RAW_WORDS);
+            load_raw(q, partials + (size_t)(b + k) * RAW_WORDS);
             add(r, acc, q);
             acc = r;
         }
     }
-    uint32_t o[32];
-    store_xyzz(o, acc);
-    st32(buckets + (size_t)b * 32, o);
+    for (uint32_t off = G >> 1; off >= 1; off >>= 1) {
+        const Xyzz o = shfl_down_xyzz(acc, off);
+        if (j < off) {
+            Xyzz r;
+            add(r, acc, o);
+            acc = r;
+        }
+    }
+    if (j == 0) {
+        uint32_t o[32];
+        store_xyzz(o, acc);
+        st32(buckets + (size_t)b * 32, o);
+    }
 }
 // K4h: one workgroup per queued bucket: strided in-lane sums, then an LDS tree
 __global__ void __launch_bounds__(MSM_THREADS) msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
@@ -626,6 +680,94 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_slice_kernel(SliceArgs A)
     st32(J.out + (size_t)t * 32, w);
 }
 
+// ---- fused K5: two launches instead of ~20 ------------------------------------------------------------------------------
+// Workgroup tree sum over up to 256 XYZZ points held one per lane (raw lazy limbs through LDS, structure of arrays):
+// the dependent chain is log2(T) additions with no launch gaps in between.  Result in lane 0.
+constexpr int FOLD_T = 256;
+__device__ __forceinline__ void wg_tree_sum(Xyzz& acc, uint32_t* sh, uint32_t T, uint32_t t)
+{
+    for (uint32_t half = T >> 1; half >= 1; half >>= 1) {
+        if (t >= half && t < 2 * half) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                sh[(0 * NL + i) * FOLD_T + t - half] = acc.x.d[i];
+                sh[(1 * NL + i) * FOLD_T + t - half] = acc.y.d[i];
+                sh[(2 * NL + i) * FOLD_T + t - half] = acc.zz.d[i];
+                sh[(3 * NL + i) * FOLD_T + t - half] = acc.zzz.d[i];
+            }
+        }
+        __syncthreads();
+        if (t < half) {
+            Xyzz q, r;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                q.x.d[i] = sh[(0 * NL + i) * FOLD_T + t];
+                q.y.d[i] = sh[(1 * NL + i) * FOLD_T + t];
+                q.zz.d[i] = sh[(2 * NL + i) * FOLD_T + t];
+                q.zzz.d[i] = sh[(3 * NL + i) * FOLD_T + t];
+            }
+            add(r, acc, q);
+            acc = r;
+        }
+        __syncthreads();
+    }
+}
+// Row sums R[hi] = sum_lo B[hi][lo] (blockIdx.x < H) and column sums C[lo] = sum_hi B[hi][lo] (blockIdx.x >= H) of the
+// H x L bucket matrix of group blockIdx.y; blockDim.x = max(H, L).
+__global__ void __launch_bounds__(FOLD_T) msm_rowcol_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
+                                                          uint32_t H, uint32_t L)
+{
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __shared__ uint32_t sh[RAW_WORDS * FOLD_T];
+    const uint32_t g = blockIdx.y, t = threadIdx.x, nb = H * L;
+    const bool row = blockIdx.x < H;
+    const uint32_t idx = row ? blockIdx.x : blockIdx.x - H, count = row ? L : H;
+    Xyzz acc;
+    set_infinity(acc);
+    if (t < count) {
+        const size_t b = row ? (size_t)idx * L + t : (size_t)t * L + idx;
+        uint32_t w[32];
+        ld32(buckets + ((size_t)g * nb + b) * 32, w);
+        load_xyzz(acc, w);
+    }
+    wg_tree_sum(acc, sh, blockDim.x, t);
+    if (t == 0) {
+        uint32_t w[32];
+        store_xyzz(w, acc);
+        st32((row ? R + ((size_t)g * H + idx) * 32 : Cc + ((size_t)g * L + idx) * 32), w);
+    }
+}
+// Job 0: Z = sum R; job 1 + k: TR_k = sum of the R_hi whose bit k is set; job 1 + hbits + k: TC_k likewise over C.  Each job is
+// one workgroup; results go straight into the 64-slot export array in the reference's Montgomery form (slot 0 = Z,
+// 1 + k = TR_k, 32 + k = TC_k; the array is zeroed = infinity beforehand).
+__global__ void __launch_bounds__(FOLD_T) msm_final_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
+                                                         uint32_t hbits, uint32_t lbits)
+{
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __shared__ uint32_t sh[RAW_WORDS * FOLD_T];
+    const uint32_t g = blockIdx.y, t = threadIdx.x, job = blockIdx.x;
+    const uint32_t H = 1u << hbits, L = 1u << lbits;
+    const uint32_t* src;
+    uint32_t count, slot, k = 0;
+    bool sliced = true;
+    if (job == 0) { src = R + (size_t)g * H * 32; count = H; slot = 0; sliced = false; }
+    else if (job < 1 + hbits) { k = job - 1; src = R + (size_t)g * H * 32; count = H >> 1; slot = 1 + k; }
+    else { k = job - 1 - hbits; src = Cc + (size_t)g * L * 32; count = L >> 1; slot = 32 + k; }
+    Xyzz acc;
+    set_infinity(acc);
+    if (t < count) {
+        uint32_t w[32];
+        ld32(src + (size_t)(sliced ? insert_one_bit(t, k) : t) * 32, w);
+        load_xyzz(acc, w);
+    }
+    wg_tree_sum(acc, sh, blockDim.x, t);
+    if (t == 0) {
+        uint32_t o[32];
+        store_xyzz_m256(o, acc);
+        st32(out + ((size_t)g * 64 + slot) * 32, o);
+    }
+}
+
 // final: per window gather Z, TR_k, TC_k into 64 slots and convert to the reference's Montgomery(2^256) words
 //   slot 0 = Z, 1 + k = TR_k (k < hbits), 32 + k = TC_k (k < lbits); unused slots are infinity
 __global__ void msm_collect_kernel(const uint32_t* __restrict__ z, const uint32_t* __restrict__ tr, const uint32_t* __restrict__ tc,
@@ -704,13 +846,15 @@ static uint32_t acc_capacity_lanes()
     }
     return lanes;
 }
-// chunk length of K4: one resident wave of workgroups covers the whole entry list (no tail wave), >= 16 entries per lane
+// chunk length of K4: one resident wave of workgroups covers the whole entry list (no tail wave), >= MIN_CHUNK entries per lane
+// (small MSMs are latency-bound: a lane's chain of `ch` dependent mixed additions is the critical path, ~5 us each)
+constexpr uint32_t MIN_CHUNK = 8;
 static uint32_t chunk_len(size_t n, uint32_t nw)
 {
     const uint64_t m = (uint64_t)n * nw;
     const uint32_t cap = acc_capacity_lanes();
     uint32_t ch = (uint32_t)((m + cap - 1) / cap);
-    return ch < 16 ? 16 : ch;
+    return ch < MIN_CHUNK ? MIN_CHUNK : ch;
 }
 static size_t arena_points(const MsmPlan& P, uint32_t nw)
 {
@@ -749,7 +893,7 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     tot += al((size_t)nw * 8 + 512);                         // totals, bases (nw + 1)
     tot += al(((size_t)nw * P.nb + 1) * 4);                  // heavy-bucket queue
     tot += al((size_t)nw * n * 4);                           // sorted
-    const size_t chunks = ((size_t)n * nw + 15) / 16 + 1;    // upper bound for any chunk length >= 16
+    const size_t chunks = ((size_t)n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1; // upper bound for any chunk length >= MIN_CHUNK
     tot += al(((size_t)nw * P.nb + chunks) * RAW_WORDS * 4); // partials
     tot += al((size_t)nw * P.nb * 128);                      // buckets
     tot += al(arena_points(P, (uint32_t)nw) * 128);          // fold arena
@@ -833,7 +977,7 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     uint32_t* totals = (uint32_t*)p; uint32_t* bases = totals + nw; p += al((size_t)nw * 8 + 512);
     uint32_t* heavy = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
     uint32_t* sorted = (uint32_t*)p; p += al((size_t)nw * n * 4);
-    const size_t chunks_cap = ((size_t)n * nw + 15) / 16 + 1;
+    const size_t chunks_cap = ((size_t)n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1;
     uint32_t* partials = (uint32_t*)p; p += al(((size_t)nw * P.nb + chunks_cap) * RAW_WORDS * 4);
     uint32_t* buckets = (uint32_t*)p; p += al((size_t)nw * P.nb * 128);
     uint32_t* scratch = (uint32_t*)p; p += al(arena_points(P, nw) * 128);
@@ -850,7 +994,7 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     }
 
     // K0
-    msm_digits_kernel<<<(P.n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>((const uint32_t*)d_scalars, digits, P.n, P.c, P.W);
+    msm_digits_kernel<<<(P.n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>((const uint32_t*)d_scalars, digits, P.n, make_layout(c, table), P.W);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
     sortA_hist_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
@@ -864,20 +1008,37 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     // K4 + K4m
     const uint32_t total_buckets = G * P.nb;
     const uint32_t ch = chunk_len(n, nw);
-    // in-lane merge limit: with one shared bucket set every bucket is cut into ~ n*nw / (nb*ch) + 1 partials
-    const uint32_t merge_light = table ? 6u + (uint32_t)(((uint64_t)n * nw) / ((uint64_t)P.nb * ch)) * 2u : 6u;
+    // merge: 2^logG lanes per bucket, sized for the expected number of partials per bucket (~ entries / (buckets * ch) + 1);
+    // a bucket cut into more than 8 partials per lane of its group is queued for the workgroup-per-bucket kernel
+    // -- but no wider than what fills the chip once (~2^16 lanes): beyond that the extra lanes only add issue work
+    const uint32_t avg_partials = (uint32_t)(((uint64_t)n * nw) / ((uint64_t)G * P.nb * ch)) + 1;
+    uint32_t logG = 0;
+    while ((1u << logG) < avg_partials && logG < 6 && ((uint64_t)G * P.nb << (logG + 1)) <= (1u << 16)) logG++;
+    const uint32_t merge_light = std::max(6u, 8u << logG);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
     msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch);
     if (tm) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
-    msm_merge_kernel<<<(total_buckets + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch, merge_light);
-    msm_merge_heavy_kernel<<<1024, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
+    msm_merge_kernel<<<(uint32_t)((((uint64_t)total_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
+                                                                                                                     total_buckets, ch, merge_light, logG);
+    msm_merge_heavy_kernel<<<256, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
     if (tm) HIPCHK(hipEventRecord(ev[4], st));
 
     // K5: bucket b = hi * 2^l + lo carries weight b + 1:
     //   S_w = Z + sum_lo lo * C_lo + 2^l * sum_hi hi * R_hi,   R = row sums (over lo), C = column sums (over hi), Z = sum R
     //   sum_hi hi * R_hi = sum_k 2^k TR_k, TR_k = sum of the R_hi whose bit k is set (same for C).
     const uint32_t H = 1u << P.hbits, L = 1u << P.lbits;
+    static const bool legacy_k5 = getenv("BBGPU_K5_LEGACY") != nullptr; // A/B knob: the per-level fold launches
+    if (!legacy_k5) {
+        // fused: row + column sums in one launch (one workgroup tree per row / column), then Z and the bit-sliced sums in a second
+        uint32_t* Rr = scratch;
+        uint32_t* Cc = scratch + (size_t)G * H * 32;
+        msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L);
+        if (tm) HIPCHK(hipEventRecord(ev[5], st));
+        HIPCHK(hipMemsetAsync(texp, 0, (size_t)G * 64 * 128, st)); // unused slots = infinity (zz = 0)
+        msm_final_kernel<<<dim3(1 + P.hbits + P.lbits, G), std::max(H, L), 0, st>>>(Rr, Cc, texp, P.hbits, P.lbits);
+        if (tm) HIPCHK(hipEventRecord(ev[6], st));
+    } else {
     uint32_t* bump = scratch;
     bool arena_overflow = false;
     auto alloc_pts = [&](size_t count) {
@@ -931,6 +1092,7 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     }
     msm_collect_kernel<<<(G * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, G, P.hbits, P.lbits);
     if (tm) HIPCHK(hipEventRecord(ev[6], st));
+    }
     HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(S.done, st));
     HIPCHK(hipGetLastError());
@@ -1014,7 +1176,7 @@ int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uin
 {
     uint32_t* d_tab = nullptr;
     HIPCHK(hipMalloc((void**)&d_tab, (size_t)num_windows * n * 64));
-    srs_table_kernel<<<(uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(d_srs, d_tab, (uint32_t)n, (uint32_t)c, (uint32_t)num_windows);
+    srs_table_kernel<<<(uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(d_srs, d_tab, (uint32_t)n, make_layout(c, true), (uint32_t)num_windows);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     *d_tab_out = d_tab;

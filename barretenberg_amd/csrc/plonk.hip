@@ -176,7 +176,7 @@ class PlonkProver {
         HIPCHK(hipMemcpyAsync(dst, src, count * 32, hipMemcpyDeviceToDevice, st));
         return BBGPU_OK;
     }
-    // commitments of `count` <= 3 resident coefficient vectors of n scalars: two MSMs in flight (msm.hip two-slot pipeline)
+    // commitments of `count` <= 3 resident coefficient vectors of n scalars, all in flight at once (msm.hip slots)
     int commit(const uint64_t* const* scalars, int count, uint64_t (*out)[8])
     {
         const double t0 = now_ms();
@@ -191,11 +191,10 @@ class PlonkProver {
             return BBGPU_OK;
         };
         for (int i = 0; i < count; i++) {
-            if (i >= 2) RC(collect(i - 2));
             ticket[i] = bbgpu_msm_g1_device_async(srs, 0, scalars[i], n, 0, W, nullptr);
             if (ticket[i] < 0) return ticket[i];
         }
-        for (int i = count >= 2 ? count - 2 : 0; i < count; i++) RC(collect(i));
+        for (int i = 0; i < count; i++) RC(collect(i));
         timing[1] += now_ms() - t0;
         return BBGPU_OK;
     }

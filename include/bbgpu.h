@@ -102,9 +102,10 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs);
 int bbgpu_msm_num_windows(size_t n);
 int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                         int window_end, uint64_t out[12], void* hip_stream);
-/* Asynchronous form: enqueue (returns a ticket 0/1, or a negative error) and collect later.  Two MSMs may be in flight;
- * the bucket-reduction tail and host finish of one then overlap the sort/accumulate of the next.  With
- * hip_stream == NULL each ticket runs on its own internal stream. */
+/* Asynchronous form: enqueue (returns a ticket >= 0, or a negative error) and collect later.  Up to four MSMs may be in
+ * flight; the bucket-reduction tail and host finish of one then overlap the sort/accumulate of the next, and
+ * small latency-bound MSMs (a prover round's three commitments) run side by side.  With hip_stream == NULL each ticket runs
+ * on its own internal stream. */
 int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                               int window_end, void* hip_stream);
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12]);
