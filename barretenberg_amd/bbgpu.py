@@ -36,6 +36,7 @@ C_ABI_SYMBOLS = [
     "bbgpu_ntt_device", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
     "bbgpu_srs_num_windows", "bbgpu_msm_g1",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_wait",
+    "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing",
     "bbgpu_set_timing",
     "bbgpu_fr_evaluate_device", "bbgpu_fr_batch_invert_device", "bbgpu_fr_product_scan_device", "bbgpu_fr_mul_device",
@@ -94,6 +95,8 @@ class BbGpu:
         L.bbgpu_msm_g1_device.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
         L.bbgpu_msm_g1_device_async.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.bbgpu_msm_g1_wait.argtypes = [C.c_int, u64p]
+        L.bbgpu_msm_g1_device_batch_async.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p]
+        L.bbgpu_msm_g1_batch_wait.argtypes = [C.c_int, u64p]
         L.bbgpu_g1_sum.argtypes = [u64p, C.c_size_t, u64p]
         L.bbgpu_last_timing.argtypes = [C.POINTER(C.c_float), C.c_int]
         vp, sz = C.c_void_p, C.c_size_t
@@ -236,6 +239,18 @@ class BbGpu:
     def msm_wait(self, ticket):
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.lib.bbgpu_msm_g1_wait(ticket, _ptr(out)))
+        return out
+
+    def msm_device_batch_async(self, handle, d_scalars_ptrs, n, offset=0, stream=None):
+        """several MSMs over the same resident points as one pass (table mode); returns a ticket for msm_batch_wait()"""
+        arr = (C.c_void_p * len(d_scalars_ptrs))(*d_scalars_ptrs)
+        t = self._chk(self.lib.bbgpu_msm_g1_device_batch_async(handle, offset, arr, len(d_scalars_ptrs), n, C.c_void_p(stream or 0)))
+        return t, len(d_scalars_ptrs)
+
+    def msm_batch_wait(self, ticket):
+        t, jobs = ticket
+        out = np.zeros((jobs, 12), dtype=np.uint64)
+        self._chk(self.lib.bbgpu_msm_g1_batch_wait(t, _ptr(out)))
         return out
 
     def g1_sum(self, points12):

@@ -12,6 +12,8 @@ void set_error(const char* fmt, ...);
 
 // ntt.hip
 int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256, hipStream_t st);
+int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256,
+                     hipStream_t st);
 void ntt_release_tables();
 
 // msm.hip
@@ -35,13 +37,16 @@ struct MsmSlot {
     hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     bool pending = false, trivial = false, timed = false;
     size_t n = 0;
-    uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0;
+    uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0, jobs = 1;
     void release();
 };
 int msm_choose_c(size_t n);
 int msm_num_windows(int c);
 int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
               int we, hipStream_t st, bool want_timing);
+int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
+                    size_t n, int wb, int we, hipStream_t st, bool want_timing);
+int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing);
 int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uint32_t** d_tab_out, hipStream_t st);
 int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st);

@@ -3,6 +3,7 @@
 // reference's concurrent pippenger() calls from an OpenMP region (scalar_multiplication.cpp:731-738) safe.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
@@ -103,7 +104,9 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs)
     e.n = n;
     e.d_srs = d_srs;
     e.live = true;
-    const int c = msm_choose_c(n), W = msm_num_windows(c);
+    int c = msm_choose_c(n);
+    if (const char* ev = getenv("BBGPU_TABLE_C")) c = std::min(16, std::max(4, atoi(ev))); // tuning knob: window size of the tables
+    const int W = msm_num_windows(c);
     if (g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24)) {
         int rc = srs_build_table(d_srs, n, c, W, &e.d_tab, g_ctx.stream);
         if (rc) return rc;
@@ -276,6 +279,29 @@ int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* con
     if (rc) return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
     rc = ntt_device(d_coeffs, g_ctx.d_scratch, lg, kind, constant, st);
+    if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^22)", lg);
+    if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, int batch, int kind, const uint64_t* constant, void* hip_stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    const int lg = log2_exact(n);
+    if (lg < 1) {
+        set_error("NTT size %zu is not a power of two >= 2", n);
+        return BBGPU_ERR_SIZE;
+    }
+    if (kind < 0 || kind > BBGPU_COSET_FFT_WITH_CONSTANT || !d_coeffs || batch < 1 || batch > 64 || stride_elems < n) {
+        set_error("bad NTT kind / null buffer / batch / stride");
+        return BBGPU_ERR_ARG;
+    }
+    rc = grow(&g_ctx.d_scratch, &g_ctx.scratch_cap, (size_t)batch * n * 32);
+    if (rc) return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    rc = ntt_device_batch(d_coeffs, stride_elems, batch, g_ctx.d_scratch, lg, kind, constant, st);
     if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^22)", lg);
     if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
     return rc;
@@ -573,6 +599,58 @@ int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_s
     if (rc) return rc;
     if (t < 2) g_ctx.next_slot = t ^ 1;
     return t;
+}
+
+int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_t* const* d_scalars, int jobs, size_t n, void* hip_stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (srs_handle < 0 || srs_handle >= (int)g_ctx.srs.size() || !g_ctx.srs[srs_handle].live) {
+        set_error("unknown SRS handle %d", srs_handle);
+        return BBGPU_ERR_ARG;
+    }
+    const SrsEntry& e = g_ctx.srs[srs_handle];
+    if (!d_scalars || jobs < 1 || offset + n > e.n) {
+        set_error("bad batch: jobs %d, range [%zu, %zu) of %zu points", jobs, offset, offset + n, e.n);
+        return BBGPU_ERR_ARG;
+    }
+    if (!e.d_tab && jobs > 1) {
+        set_error("batched MSM needs an SRS registered with window tables (bbgpu_set_precompute, 1024 <= n <= 2^20)");
+        return BBGPU_ERR_ARG;
+    }
+    int t = -1;
+    const int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1, 2, 3 };
+    for (int k = 0; k < Context::NSLOT; k++)
+        if (!g_ctx.slot[order[k]].pending) { t = order[k]; break; }
+    if (t < 0) {
+        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
+        return BBGPU_ERR_STATE;
+    }
+    MsmSlot& S = g_ctx.slot[t];
+    if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
+    rc = msm_issue_batch(S, e.d_srs + offset * 16, e.d_tab ? e.d_tab + offset * 16 : nullptr, e.n, e.tab_c, d_scalars, jobs, n, 0, entry_windows(e, n), st,
+                         g_ctx.timing);
+    if (rc) return rc;
+    if (t < 2) g_ctx.next_slot = t ^ 1;
+    return t;
+}
+
+int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending || !out) {
+        set_error("no MSM batch in flight for ticket %d", ticket);
+        return BBGPU_ERR_ARG;
+    }
+    MsmSlot& S = g_ctx.slot[ticket];
+    host::Xyzz res[4];
+    const uint32_t jobs = S.jobs;
+    int rc = msm_finish_batch(S, res, &g_ctx.last);
+    if (rc) return rc;
+    for (uint32_t j = 0; j < jobs; j++) host::g1_to_normalised(res[j], out + 12 * j);
+    return BBGPU_OK;
 }
 
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12])

@@ -39,6 +39,7 @@ using Fr = FrP;
 constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
 constexpr int MSM_MAX_C = 16;    // digits stored as int16, LDS histogram of 2^15 counters
 constexpr int MSM_THREADS = 256;
+constexpr int MSM_MAX_JOBS = 4;  // MSMs over the same points issued as one batch (one bucket set each)
 
 __device__ __forceinline__ void ld8(const uint32_t* p, uint32_t (&w)[8])
 {
@@ -256,11 +257,16 @@ __global__ void srs_gen_points_kernel(const uint32_t* __restrict__ tab, Limbs9 x
 //     254 = 21 * 12 + 2 would leave a 2-bit top window whose n entries all land in 3 buckets (measured at n = 2^16: one
 //     workgroup of the sort and the heavy-bucket merge became the critical path, 130 us of a 570 us MSM).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
+struct ScalarSets {
+    const uint32_t* p[MSM_MAX_JOBS]; // one scalar vector per job of a batch (blockIdx.y)
+};
+__global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, int16_t* __restrict__ digits_all,
                                                                uint32_t n, WinLayout LO, uint32_t num_windows)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint32_t* __restrict__ scalars = sets.p[blockIdx.y];
+    int16_t* __restrict__ digits = digits_all + (size_t)blockIdx.y * num_windows * n;
     uint32_t w[8], k[9];
     ld8(scalars + (size_t)i * 8, w);
     to_canonical(mul(unpack<Fr>(w), fe_from<Fr>(Fr::M256_TO_PLAIN)), w); // x*2^256 * 2^5 / 2^261 = x, canonical
@@ -381,7 +387,7 @@ __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(3
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                    uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
                                                                    uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
-                                                                   uint32_t idx_stride)
+                                                                   uint32_t idx_stride, uint32_t windows_per_job)
 {
     __shared__ uint32_t lc[SORT_THREADS];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(3
     for (uint32_t k = 0; k < wpg; k++) {
         const uint32_t wabs = win0 + wl * wpg + k;
         const int16_t* dg = digits + (size_t)wabs * n;
-        const uint32_t row = wabs * idx_stride; // row of the pre-shifted table (0 without tables)
+        const uint32_t row = (wabs % windows_per_job) * idx_stride; // row of the pre-shifted table (0 without tables); batches repeat the windows per job
         for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
             const int d = dg[i];
             if (d) {
@@ -884,7 +890,7 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     MsmPlan P = make_plan(n, c);
     size_t tot = 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    tot += al((size_t)P.W * n * 2);                          // digits
+    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * n * 2); // digits (a batch of j jobs passes nw = j * W)
     tot += al((size_t)nw * P.slices * 1024 * 4);             // pass-A histogram / cursors (<= 1024 bins)
     tot += al((size_t)nw * 1024 * 4 + 256);                  // bin starts
     tot += al((size_t)nw * 1024 * 4 + 256);                  // bin totals
@@ -931,7 +937,18 @@ void MsmWorkspace::release()
 int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
               int we, hipStream_t st, bool want_timing)
 {
+    return msm_issue_batch(S, d_srs, d_tab, tab_stride, tab_c, &d_scalars, 1, n, wb, we, st, want_timing);
+}
+
+// `jobs` MSMs of n scalars each over the SAME points as one pass through the pipeline (the prover's 3 / 1 / 3 / 2
+// commitments per round, prover.cpp:65-122,650-658): each job is a bucket set ("group") of the shared sort / accumulate / merge /
+// reduction kernels, so the batch costs one chain of launches and one chain of dependent group additions instead of `jobs`.
+// Table mode and the full window range only.  msm_finish_batch returns one point per job.
+int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
+                    size_t n, int wb, int we, hipStream_t st, bool want_timing)
+{
     MsmWorkspace& ws = S.ws;
+    S.jobs = (uint32_t)jobs;
     S.n = n;
     S.pending = false;
     S.timed = false;
@@ -945,9 +962,14 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     const int c = table ? tab_c : msm_choose_c(n);
     const MsmPlan P = make_plan(n, c);
     if (wb < 0 || we > (int)P.W || wb >= we) return BBGPU_ERR_ARG;
-    const uint32_t nw = (uint32_t)(we - wb);      // windows processed
-    const uint32_t G = table ? 1u : nw;           // bucket sets ("groups")
-    const uint32_t wpg = table ? nw : 1u;         // windows per group
+    if (jobs < 1 || jobs > MSM_MAX_JOBS || (jobs > 1 && (!table || wb != 0 || we != (int)P.W))) {
+        set_error("batched MSM: 1..%d jobs, window tables and the full window range required", MSM_MAX_JOBS);
+        return BBGPU_ERR_ARG;
+    }
+    const uint32_t nw1 = (uint32_t)(we - wb);     // windows processed per job
+    const uint32_t nw = nw1 * (uint32_t)jobs;     // (job, window) pairs: what the entry count and the workspace scale with
+    const uint32_t G = table ? (uint32_t)jobs : nw1; // bucket sets ("groups")
+    const uint32_t wpg = table ? nw1 : 1u;        // windows per group
     // one shared bucket set holds nw times the entries: finer bins (<= 1024) keep pass B's per-workgroup share small
     uint32_t sort_lb = P.sort_lb, sort_bins = P.sort_bins;
     if (table) {
@@ -955,8 +977,8 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
         if (const char* e = getenv("BBGPU_SORT_BINS")) want_bins = std::min(1024, std::max(64, atoi(e))); // tuning knob
         while (sort_bins < want_bins && sort_lb > 3) { sort_lb--; sort_bins <<= 1; }
     }
-    uint32_t slices = table ? std::max<uint32_t>(1, P.slices * nw / 2) : P.slices;
-    if (const char* e = getenv("BBGPU_SLICES")) slices = std::min<uint32_t>(std::max(1, atoi(e)), P.slices * nw); // tuning knob
+    uint32_t slices = table ? std::max<uint32_t>(1, P.slices * nw1 / 2) : P.slices;
+    if (const char* e = getenv("BBGPU_SLICES")) slices = std::min<uint32_t>(std::max(1, atoi(e)), P.slices * nw1); // tuning knob
     const uint32_t slice_len = (uint32_t)((n + slices - 1) / slices);
     const uint32_t idx_stride = table ? (uint32_t)tab_stride : 0u;
     const uint32_t* points = table ? d_tab : d_srs;
@@ -968,7 +990,7 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     uint8_t* p = ws.base;
-    int16_t* digits = (int16_t*)p; p += al((size_t)P.W * n * 2);
+    int16_t* digits = (int16_t*)p; p += al((size_t)std::max<size_t>(P.W, nw) * n * 2);
     uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * 1024 * 4);
     uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
     uint32_t* bintot = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
@@ -994,7 +1016,9 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     }
 
     // K0
-    msm_digits_kernel<<<(P.n + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, 0, st>>>((const uint32_t*)d_scalars, digits, P.n, make_layout(c, table), P.W);
+    ScalarSets sets{};
+    for (int j = 0; j < jobs; j++) sets.p[j] = (const uint32_t*)d_scalars_v[j];
+    msm_digits_kernel<<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, digits, P.n, make_layout(c, table), P.W);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
     sortA_hist_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
@@ -1002,7 +1026,7 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
     sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
     sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
     sortA_scatter_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
-                                                                   slice_len, (uint32_t)wb, wpg, idx_stride);
+                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W);
     sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     if (tm) HIPCHK(hipEventRecord(ev[2], st));
     // K4 + K4m
@@ -1102,32 +1126,22 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
 
 // Waits for an issued MSM and finishes it on the host:
 //   S_w = Z + sum_k 2^k TC_k + 2^l sum_k 2^k TR_k ;  result = sum_w 2^(c (wb + w)) S_w   (Horner from the top)
-int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing)
+static host::Xyzz group_sum(const MsmSlot& S, uint32_t w)
 {
-    *result = host::g1_infinity();
-    if (!S.pending) return BBGPU_ERR_STATE;
-    S.pending = false;
-    if (S.trivial) return BBGPU_OK;
-    HIPCHK(hipEventSynchronize(S.done));
-    const uint32_t nw = S.nw;
-    auto pt = [&](uint32_t w, uint32_t slot) {
+    auto pt = [&](uint32_t slot) {
         host::Xyzz q;
         memcpy(&q, (const uint8_t*)S.ws.h_out + ((size_t)w * 64 + slot) * 128, 128);
         return q;
     };
-    host::Xyzz acc = host::g1_infinity();
-    for (int w = (int)nw - 1; w >= 0; --w) {
-        host::Xyzz rs = host::g1_infinity();
-        for (int k = (int)S.hbits - 1; k >= 0; --k) rs = host::g1_add(host::g1_dbl(rs), pt(w, 1 + k));
-        for (uint32_t k = 0; k < S.lbits; k++) rs = host::g1_dbl(rs);
-        host::Xyzz cs = host::g1_infinity();
-        for (int k = (int)S.lbits - 1; k >= 0; --k) cs = host::g1_add(host::g1_dbl(cs), pt(w, 32 + k));
-        host::Xyzz sw = host::g1_add(host::g1_add(rs, cs), pt(w, 0));
-        for (uint32_t k = 0; k < S.c; k++) acc = host::g1_dbl(acc);
-        acc = host::g1_add(acc, sw);
-    }
-    for (uint32_t k = 0; k < S.c * S.wb; k++) acc = host::g1_dbl(acc);
-    *result = acc;
+    host::Xyzz rs = host::g1_infinity();
+    for (int k = (int)S.hbits - 1; k >= 0; --k) rs = host::g1_add(host::g1_dbl(rs), pt(1 + k));
+    for (uint32_t k = 0; k < S.lbits; k++) rs = host::g1_dbl(rs);
+    host::Xyzz cs = host::g1_infinity();
+    for (int k = (int)S.lbits - 1; k >= 0; --k) cs = host::g1_add(host::g1_dbl(cs), pt(32 + k));
+    return host::g1_add(host::g1_add(rs, cs), pt(0));
+}
+static int finish_timing(MsmSlot& S, MsmTiming* timing)
+{
     if (S.timed && timing) {
         float ms;
         timing->count = 0;
@@ -1139,6 +1153,35 @@ int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing)
         }
     }
     return BBGPU_OK;
+}
+int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing)
+{
+    *result = host::g1_infinity();
+    if (!S.pending) return BBGPU_ERR_STATE;
+    if (S.jobs > 1) return BBGPU_ERR_STATE; // a batch is collected with msm_finish_batch
+    S.pending = false;
+    if (S.trivial) return BBGPU_OK;
+    HIPCHK(hipEventSynchronize(S.done));
+    host::Xyzz acc = host::g1_infinity();
+    for (int w = (int)S.nw - 1; w >= 0; --w) {
+        for (uint32_t k = 0; k < S.c; k++) acc = host::g1_dbl(acc);
+        acc = host::g1_add(acc, group_sum(S, (uint32_t)w));
+    }
+    for (uint32_t k = 0; k < S.c * S.wb; k++) acc = host::g1_dbl(acc);
+    *result = acc;
+    return finish_timing(S, timing);
+}
+// one result per job of a batch (table mode: every job is one bucket set, no positional doublings)
+int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing)
+{
+    if (S.jobs <= 1) return msm_finish(S, results, timing); // a batch of one is an ordinary MSM (any mode)
+    if (!S.pending) return BBGPU_ERR_STATE;
+    S.pending = false;
+    for (uint32_t j = 0; j < S.jobs; j++) results[j] = host::g1_infinity();
+    if (S.trivial) return BBGPU_OK;
+    HIPCHK(hipEventSynchronize(S.done));
+    for (uint32_t j = 0; j < S.jobs; j++) results[j] = group_sum(S, j);
+    return finish_timing(S, timing);
 }
 
 void MsmSlot::release()

@@ -96,6 +96,8 @@ struct NttPassArgs {
     uint32_t lo_bits;         // split of the two-level tables
     uint32_t b_fast;          // 1: consecutive threads walk b first (column pass), 0: a first (row pass)
     uint32_t debug_skip;      // timing experiments only (BBGPU_NTT_SKIP): 1 = skip stages, 2 = skip twist/post multiplies
+    uint32_t batch;           // transforms in this launch (blockIdx.y): transform j works on in + j * in_bstride -> out + j * out_bstride
+    size_t in_bstride, out_bstride; // in words
 };
 
 // FLAGS: 1 = pre-scale input by scale tables (coset_fft), 2 = twist output (pass 1 of 2),
@@ -113,7 +115,7 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
         if (A.b_fast) { c = e & (cols - 1); a = e >> A.log_cols; } else { a = e & (S - 1); c = e >> A.log_s; }
         const size_t gidx = (size_t)a * A.in_sa + (size_t)(b0 + c) * A.in_sb;
         uint32_t w[8];
-        load8(A.in + 8 * gidx, w);
+        load8(A.in + (size_t)blockIdx.y * A.in_bstride + 8 * gidx, w);
         FrL x = unpack<Fr>(w);
         if constexpr (FLAGS & 1) {
             const uint32_t i = (uint32_t)gidx; // natural coefficient index
@@ -249,7 +251,7 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
             }
             to_canonical(r, w);
         }
-        store8(A.out + 8 * gidx, w);
+        store8(A.out + (size_t)blockIdx.y * A.out_bstride + 8 * gidx, w);
     }
 }
 
@@ -391,7 +393,7 @@ template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st
         (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
         attr_set = true;
     }
-    ntt_pass_kernel<FLAGS><<<blocks, NTT_THREADS, lds, st>>>(A);
+    ntt_pass_kernel<FLAGS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(A);
     return hipGetLastError();
 }
 
@@ -411,6 +413,15 @@ hipError_t dispatch(int flags, const NttPassArgs& A, hipStream_t st)
 // kind: bbgpu_ntt_kind; d_coeffs: n x 32 B device buffer, transformed in place; d_scratch: n x 32 B (only n > 2^11)
 int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256, hipStream_t st)
 {
+    return ntt_device_batch(d_coeffs, (size_t)1 << log2n, 1, d_scratch, log2n, kind, constant_m256, st);
+}
+// `batch` independent transforms of the same size and kind in the same launches (small transforms are latency-bound: a
+// 2^18-point pass occupies half the CUs for ~40 us, three of them side by side take no longer).  Transform j lives at
+// d_coeffs + j * stride_elems elements; d_scratch: batch * n x 32 B.
+int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256,
+                     hipStream_t st)
+{
+    if (batch < 1) return BBGPU_ERR_ARG;
     if (log2n < 1 || log2n > 2 * NTT_MAX_LOG_SUB) return BBGPU_ERR_SIZE;
     DomainTables* D;
     if (get_domain(log2n, st, &D) != hipSuccess) return BBGPU_ERR_HIP;
@@ -438,6 +449,7 @@ int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, con
 
     const uint32_t n1 = 1u << D->log_s1, n2 = 1u << D->log_s2;
     NttPassArgs A{};
+    A.batch = (uint32_t)batch;
     if (const char* e = getenv("BBGPU_NTT_SKIP")) A.debug_skip = (uint32_t)atoi(e);
     A.lo_bits = D->lo_bits;
     A.twist_lo = D->twist_lo[inverse];
@@ -450,6 +462,7 @@ int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, con
     if (D->log_s2 == 0) { // single pass, everything in one workgroup's LDS
         A.in = (const uint32_t*)d_coeffs;
         A.out = (uint32_t*)d_coeffs;
+        A.in_bstride = A.out_bstride = stride_elems * 8;
         A.tw_sub = D->tw_sub[inverse][0];
         A.log_s = D->log_s1; A.log_b = 0; A.cols = 1; A.log_cols = 0;
         A.in_sa = 1; A.in_sb = 0; A.out_sa = 1; A.out_sb = 0; A.b_fast = 0;
@@ -460,6 +473,8 @@ int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, con
     // pass 1: columns (a = j1, b = j2), coeffs -> scratch, same layout
     A.in = (const uint32_t*)d_coeffs;
     A.out = (uint32_t*)d_scratch;
+    A.in_bstride = stride_elems * 8;
+    A.out_bstride = ((size_t)1 << log2n) * 8;
     A.tw_sub = D->tw_sub[inverse][0];
     A.log_s = D->log_s1; A.log_b = D->log_s2;
     A.cols = NTT_LDS_ELEMS >> D->log_s1; if (A.cols > n2) A.cols = n2;
@@ -469,6 +484,8 @@ int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, con
     // pass 2: rows (a = j2, b = k1), scratch -> coeffs transposed: X[k1 + n1 * k2]
     A.in = (const uint32_t*)d_scratch;
     A.out = (uint32_t*)d_coeffs;
+    A.in_bstride = ((size_t)1 << log2n) * 8;
+    A.out_bstride = stride_elems * 8;
     A.tw_sub = D->tw_sub[inverse][1];
     A.log_s = D->log_s2; A.log_b = D->log_s1;
     A.cols = NTT_LDS_ELEMS >> D->log_s2; if (A.cols > n1) A.cols = n1;

@@ -133,22 +133,33 @@ class PlonkProver {
         const uint64_t* hw[3] = { c->w_l, c->w_r, c->w_o };
         const uint32_t* hm[3] = { c->sigma_1_mapping, c->sigma_2_mapping, c->sigma_3_mapping };
         const uint64_t* hq[5] = { c->q_m, c->q_l, c->q_r, c->q_o, c->q_c };
+        // the three wire / sigma polynomials (and the five selectors) sit back to back so that their transforms run as one
+        // batched launch (bbgpu_ntt_device_batch): at these sizes a single transform leaves most of the chip idle
+        RC(dalloc(&w_lagrange[0], 3 * fb));
+        RC(dalloc(&sigma_lagrange[0], 3 * fb));
+        RC(dalloc(&w[0], 3 * fb));
+        RC(dalloc(&sigma[0], 3 * fb));
+        RC(dalloc(&w_fft[0], 12 * fb));
+        RC(dalloc(&s_fft[0], 12 * fb));
         for (int k = 0; k < 3; k++) {
-            RC(dalloc(&w_lagrange[k], fb));
+            w_lagrange[k] = w_lagrange[0] + (size_t)k * n * 4;
+            sigma_lagrange[k] = sigma_lagrange[0] + (size_t)k * n * 4;
+            w[k] = w[0] + (size_t)k * n * 4;
+            sigma[k] = sigma[0] + (size_t)k * n * 4;
+            w_fft[k] = w_fft[0] + (size_t)k * 4 * n * 4;
+            s_fft[k] = s_fft[0] + (size_t)k * 4 * n * 4;
             RC(dalloc(&sigma_mapping[k], n * 4));
-            RC(dalloc(&sigma_lagrange[k], fb));
-            RC(dalloc(&w[k], fb));
-            RC(dalloc(&sigma[k], fb));
-            RC(dalloc(&w_fft[k], 4 * fb));
-            RC(dalloc(&s_fft[k], 4 * fb));
             RC(dalloc(&tmp[k], fb));
             HIPCHK(hipMemcpy(w_lagrange[k], hw[k], fb, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(sigma_mapping[k], hm[k], n * 4, hipMemcpyHostToDevice));
         }
+        RC(dalloc(&q_lagrange[0], 5 * fb));
+        RC(dalloc(&q_coeff[0], 5 * fb));
+        RC(dalloc(&q_fft2n[0], 10 * fb));
         for (int k = 0; k < 5; k++) {
-            RC(dalloc(&q_lagrange[k], fb));
-            RC(dalloc(&q_coeff[k], fb));
-            RC(dalloc(&q_fft2n[k], 2 * fb));
+            q_lagrange[k] = q_lagrange[0] + (size_t)k * n * 4;
+            q_coeff[k] = q_coeff[0] + (size_t)k * n * 4;
+            q_fft2n[k] = q_fft2n[0] + (size_t)k * 2 * n * 4;
             HIPCHK(hipMemcpy(q_lagrange[k], hq[k], fb, hipMemcpyHostToDevice));
         }
         RC(dalloc(&roots, fb));
@@ -171,30 +182,42 @@ class PlonkProver {
 
     // ---- small helpers ----------------------------------------------------------------------------------------------
     int ntt(uint64_t* d, size_t size, int kind, const Fr* c = nullptr) { return bbgpu_ntt_device(d, size, kind, c ? c->d : nullptr, st); }
+    // `batch` transforms of consecutive polynomials (the contiguous triples / quintuples above)
+    int ntt_batch(uint64_t* d, size_t size, int batch, int kind, const Fr* c = nullptr)
+    {
+        return bbgpu_ntt_device_batch(d, size, size, batch, kind, c ? c->d : nullptr, st);
+    }
     int copy(uint64_t* dst, const uint64_t* src, size_t count)
     {
         HIPCHK(hipMemcpyAsync(dst, src, count * 32, hipMemcpyDeviceToDevice, st));
         return BBGPU_OK;
     }
-    // commitments of `count` <= 3 resident coefficient vectors of n scalars, all in flight at once (msm.hip slots)
+    // commitments of `count` <= 3 resident coefficient vectors of n scalars: one batched pass (bbgpu_msm_g1_device_batch_async);
+    // without window tables on the SRS, side-by-side single MSMs
     int commit(const uint64_t* const* scalars, int count, uint64_t (*out)[8])
     {
         const double t0 = now_ms();
         HIPCHK(hipStreamSynchronize(st)); // the scalars are produced on our stream; the MSM slots run on their own
-        const int W = bbgpu_srs_num_windows(srs, n);
-        if (W < 0) return W;
-        int ticket[3] = { -1, -1, -1 };
-        uint64_t res[12];
-        auto collect = [&](int i) -> int {
-            RC(bbgpu_msm_g1_wait(ticket[i], res));
-            memcpy(out[i], res, 64); // normalised: x, y canonical (an infinity flag would sit in bit 63 of y limb 3)
-            return BBGPU_OK;
-        };
-        for (int i = 0; i < count; i++) {
-            ticket[i] = bbgpu_msm_g1_device_async(srs, 0, scalars[i], n, 0, W, nullptr);
-            if (ticket[i] < 0) return ticket[i];
+        uint64_t res[4 * 12];
+        int ticket = bbgpu_msm_g1_device_batch_async(srs, 0, scalars, count, n, nullptr);
+        if (ticket >= 0) {
+            RC(bbgpu_msm_g1_batch_wait(ticket, res));
+            for (int i = 0; i < count; i++) memcpy(out[i], res + 12 * i, 64); // normalised: x, y canonical
+        } else if (ticket == BBGPU_ERR_ARG) {
+            const int W = bbgpu_srs_num_windows(srs, n);
+            if (W < 0) return W;
+            int tk[3] = { -1, -1, -1 };
+            for (int i = 0; i < count; i++) {
+                tk[i] = bbgpu_msm_g1_device_async(srs, 0, scalars[i], n, 0, W, nullptr);
+                if (tk[i] < 0) return tk[i];
+            }
+            for (int i = 0; i < count; i++) {
+                RC(bbgpu_msm_g1_wait(tk[i], res));
+                memcpy(out[i], res, 64);
+            }
+        } else {
+            return ticket;
         }
-        for (int i = 0; i < count; i++) RC(collect(i));
         timing[1] += now_ms() - t0;
         return BBGPU_OK;
     }
@@ -237,12 +260,11 @@ class PlonkProver {
         const Fr root = host::fr_root_of_unity(log2n);
         RC(poly::powers(roots, n, root, host::fr_one(), st));
         for (int k = 0; k < 3; k++) RC(poly::sigma_from_mapping(sigma_lagrange[k], sigma_mapping[k], roots, n, st)); // prover.cpp:663-665
-        for (int k = 0; k < 5; k++) { // arithmetic_widget.cpp:68-84 without the alpha scaling (applied in quotient_mid)
-            RC(copy(q_coeff[k], q_lagrange[k], n));
-            RC(ntt(q_coeff[k], n, BBGPU_IFFT));
-            RC(poly::copy_pad(q_fft2n[k], q_coeff[k], n, 2 * n, st));
-            RC(ntt(q_fft2n[k], 2 * n, BBGPU_COSET_FFT));
-        }
+        // arithmetic_widget.cpp:68-84 without the alpha scaling (applied in quotient_mid)
+        RC(copy(q_coeff[0], q_lagrange[0], 5 * n));
+        RC(ntt_batch(q_coeff[0], n, 5, BBGPU_IFFT));
+        for (int k = 0; k < 5; k++) RC(poly::copy_pad(q_fft2n[k], q_coeff[k], n, 2 * n, st));
+        RC(ntt_batch(q_fft2n[0], 2 * n, 5, BBGPU_COSET_FFT));
         RC(poly::lagrange_l1_fft(l_1, quotient_mid, log2n, log2n + 1, scratch, st)); // prover.cpp:350-351 (quotient_mid as workspace)
         HIPCHK(hipStreamSynchronize(st));
         circuit_ready = true;
@@ -253,10 +275,8 @@ class PlonkProver {
     // prover.cpp:124-133
     int compute_wire_coefficients()
     {
-        for (int k = 0; k < 3; k++) {
-            RC(copy(w[k], w_lagrange[k], n));
-            RC(ntt(w[k], n, BBGPU_IFFT));
-        }
+        RC(copy(w[0], w_lagrange[0], 3 * n));
+        RC(ntt_batch(w[0], n, 3, BBGPU_IFFT));
         return BBGPU_OK;
     }
     // prover.cpp:65-86
@@ -285,13 +305,16 @@ class PlonkProver {
         A.num = (uint32_t*)tmp[0]; A.den = (uint32_t*)tmp[1];
         A.n = (uint32_t)n;
         RC(poly::z_terms(A, host::fr_root_of_unity(log2n), challenges.beta, challenges.gamma, st));
-        RC(poly::product_scan(tmp[0], tmp[2], n, false, false, scratch, st, nullptr)); // PN -> tmp[2]
-        RC(poly::product_scan(tmp[1], tmp[0], n, true, true, scratch, st, slots));      // SD -> tmp[0], total -> slot 0
+        // PN: exclusive prefix products of num -> tmp[2];  SD: inclusive suffix products of den -> r (free at this point), total -> slot 0
+        poly::ScanJob sj[2] = {};
+        sj[0].in = tmp[0]; sj[0].out = tmp[2]; sj[0].n = n; sj[0].reverse = false; sj[0].inclusive = false;
+        sj[1].in = tmp[1]; sj[1].out = r; sj[1].n = n; sj[1].reverse = true; sj[1].inclusive = true; sj[1].d_total = slots;
+        RC(poly::scan_pair(0, sj, 2, scratch, st));
         HIPCHK(hipMemcpyAsync(h_slots, slots, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         Fr total;
         memcpy(total.d, h_slots, 32);
-        RC(poly::mul2c(z, tmp[2], tmp[0], n, host::fr_inv(total), st));
+        RC(poly::mul2c(z, tmp[2], r, n, host::fr_inv(total), st));
         RC(ntt(z, n, BBGPU_IFFT));
         return BBGPU_OK;
     }
@@ -309,16 +332,12 @@ class PlonkProver {
     int compute_quotient_numerators()
     {
         const size_t n4 = 4 * n, n2 = 2 * n;
-        for (int k = 0; k < 3; k++) { // prover.cpp:418-425
-            RC(poly::copy_pad(w_fft[k], w[k], n, n4, st));
-            RC(ntt(w_fft[k], n4, BBGPU_COSET_FFT));
-        }
-        for (int k = 0; k < 3; k++) { // :245-247, :253-276
-            RC(copy(sigma[k], sigma_lagrange[k], n));
-            RC(ntt(sigma[k], n, BBGPU_IFFT_WITH_CONSTANT, &challenges.beta));
-            RC(poly::sigma_prepare(s_fft[k], sigma[k], w[k], n, n4, challenges.gamma, st));
-            RC(ntt(s_fft[k], n4, BBGPU_COSET_FFT));
-        }
+        for (int k = 0; k < 3; k++) RC(poly::copy_pad(w_fft[k], w[k], n, n4, st)); // prover.cpp:418-425
+        RC(ntt_batch(w_fft[0], n4, 3, BBGPU_COSET_FFT));
+        RC(copy(sigma[0], sigma_lagrange[0], 3 * n)); // :245-247, :253-276
+        RC(ntt_batch(sigma[0], n, 3, BBGPU_IFFT_WITH_CONSTANT, &challenges.beta));
+        for (int k = 0; k < 3; k++) RC(poly::sigma_prepare(s_fft[k], sigma[k], w[k], n, n4, challenges.gamma, st));
+        RC(ntt_batch(s_fft[0], n4, 3, BBGPU_COSET_FFT));
         RC(poly::copy_pad(z_fft, z, n, n4, st)); // :440
         RC(ntt(z_fft, n4, BBGPU_COSET_FFT_WITH_CONSTANT, &challenges.alpha)); // :278
         poly::QuotLargeArgs L{};
@@ -383,13 +402,11 @@ class PlonkProver {
         const Fr beta_inv = host::fr_inv(challenges.beta);
         const Fr shifted_z = host::fr_mul(zc, host::fr_root_of_unity(log2n));
         // seven evaluations, one read-back (:478-480, :504-506, :512)
-        RC(poly::evaluate_to_device(w[0], n, zc, slots + 0 * 4, scratch, st));
-        RC(poly::evaluate_to_device(w[1], n, zc, slots + 1 * 4, scratch, st));
-        RC(poly::evaluate_to_device(w[2], n, zc, slots + 2 * 4, scratch, st));
-        RC(poly::evaluate_to_device(sigma[0], n, zc, slots + 3 * 4, scratch, st));
-        RC(poly::evaluate_to_device(sigma[1], n, zc, slots + 4 * 4, scratch, st));
-        RC(poly::evaluate_to_device(z, n, shifted_z, slots + 5 * 4, scratch, st));
-        RC(poly::evaluate_to_device(quotient_large, 3 * n, zc, slots + 6 * 4, scratch, st));
+        const Fr zs[2] = { zc, shifted_z };
+        const poly::EvalJob ej[7] = { { w[0], n, 0, slots + 0 * 4 }, { w[1], n, 0, slots + 1 * 4 }, { w[2], n, 0, slots + 2 * 4 },
+                                      { sigma[0], n, 0, slots + 3 * 4 }, { sigma[1], n, 0, slots + 4 * 4 }, { z, n, 1, slots + 5 * 4 },
+                                      { quotient_large, 3 * n, 0, slots + 6 * 4 } };
+        RC(poly::evaluate_batch_to_device(ej, 7, zs, scratch, st));
         HIPCHK(hipMemcpyAsync(h_slots, slots, 7 * 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         Fr ev[7];
@@ -466,9 +483,11 @@ class PlonkProver {
         // compute_kate_opening_coefficients (polynomial_arithmetic.cpp:562-591): W_i = sum_{j>i} F_j z^(j-i-1); the serial
         // recurrence becomes a Horner suffix scan, the remainder F(z) drops out
         const Fr shifted_z = host::fr_mul(challenges.z, host::fr_root_of_unity(log2n));
-        RC(poly::horner_suffix(tmp[0], tmp[2], n, challenges.z, false, scratch, st, nullptr));
-        RC(poly::horner_suffix(tmp[1], tmp[0], n, shifted_z, false, scratch, st, nullptr));
-        const uint64_t* sc[2] = { tmp[2], tmp[0] };
+        poly::ScanJob kj[2] = {};
+        kj[0].in = tmp[0]; kj[0].out = tmp[2]; kj[0].n = n; kj[0].reverse = true; kj[0].inclusive = false; kj[0].z = challenges.z;
+        kj[1].in = tmp[1]; kj[1].out = r; kj[1].n = n; kj[1].reverse = true; kj[1].inclusive = false; kj[1].z = shifted_z;
+        RC(poly::scan_pair(1, kj, 2, scratch, st));
+        const uint64_t* sc[2] = { tmp[2], r };
         uint64_t out[2][8];
         RC(commit(sc, 2, out)); // :650-658
         memcpy(proof.PI_Z, out[0], 64);

@@ -54,7 +54,34 @@ struct LinCombArgs {
     int count;
 };
 
+struct EvalJob {
+    const uint64_t* coeffs;
+    size_t n;
+    int zsel;           // evaluate at z[zsel]
+    uint64_t* d_result; // 32-byte device slot
+};
+struct EvalBatchArgs {
+    const uint32_t* c[8];
+    uint32_t* result[8];
+    uint32_t n[8], blocks[8];
+    uint8_t zsel[8];
+    Limbs9 zT[8];
+    PowTab T[2];
+    uint32_t* partial; // 8 x 256 elements
+};
+struct ScanJob {
+    const uint64_t* in;
+    uint64_t* out;      // may be null when only the total is wanted
+    size_t n;
+    bool reverse, inclusive;
+    host::Fr z;         // Horner scans only
+    uint64_t* d_total;  // optional 32-byte device slot
+};
+
 PowTab make_powtab(const host::Fr& base);
+// up to two scans of the same kind in shared launches: mode 0 = running products, mode 1 = Horner suffix sums
+int scan_pair(int mode, const ScanJob* jobs, int count, Scratch& S, hipStream_t st);
+int evaluate_batch_to_device(const EvalJob* jobs, int count, const host::Fr z[2], Scratch& S, hipStream_t st);
 
 int powers(uint64_t* d_out, size_t n, const host::Fr& base, const host::Fr& start, hipStream_t st);
 int copy_pad(uint64_t* d_dst, const uint64_t* d_src, size_t n_src, size_t n_dst, hipStream_t st);

@@ -233,9 +233,12 @@ template <int MODE> __device__ __forceinline__ FrV ld_or_id(const uint32_t* p, u
 }
 
 // phase 1: per-thread run totals, block scan of them -> tpart (exclusive within the block), bpart (block total)
-template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase1(ScanArgs A)
+// (two independent scans per launch: blockIdx.y selects the argument block; the second may be empty, n = 0)
+template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase1(ScanArgs A0, ScanArgs A1)
 {
     __shared__ uint32_t sh[NL * SCAN_T];
+    const ScanArgs& A = blockIdx.y ? A1 : A0;
+    if (blockIdx.x * SCAN_BLOCK >= A.n) return; // whole workgroup: the two scans may differ in length
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t base = b * SCAN_BLOCK + t * RUN;
     const bool suffix = (MODE == 1) || A.reverse;
@@ -261,8 +264,9 @@ template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase1(Scan
 }
 
 // phase 3: out_i from the block carry, the thread partial and the in-run elements
-template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase3(ScanArgs A)
+template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase3(ScanArgs A0, ScanArgs A1)
 {
+    const ScanArgs& A = blockIdx.y ? A1 : A0;
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t base = b * SCAN_BLOCK + t * RUN;
     if (base >= A.n) return;
@@ -388,6 +392,83 @@ __global__ void __launch_bounds__(PT) k_sum_small(const uint32_t* __restrict__ p
 #pragma unroll
         for (int k = 0; k < NL; k++) s.d[k] = sh[k * PT];
         stv(out, 0, s);
+    }
+}
+
+// several evaluations in one pair of launches (blockIdx.y = job): the prover's seven openings at z / z w (prover.cpp:478-512)
+__global__ void __launch_bounds__(PT) k_eval_partial_batch(EvalBatchArgs A)
+{
+    __shared__ uint32_t sh[NL * PT];
+    const uint32_t job = blockIdx.y;
+    const uint32_t n = A.n[job], nblocks = A.blocks[job];
+    if (blockIdx.x >= nblocks) return;
+    const uint32_t* __restrict__ c = A.c[job];
+    const PowTab& T = A.T[A.zsel[job]];
+    const uint32_t nt = nblocks * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    FrM acc = mul(fe_zero<Fr>(), fe_from<Fr>(Fr::ONE));
+    if (t < n) {
+        const uint32_t cnt = (n - t + nt - 1) / nt;
+        const FrC zT = cst(A.zT[job]);
+        FrH h = ldv(c, t + (size_t)(cnt - 1) * nt);
+        for (uint32_t k = cnt - 1; k-- > 0;) h = add(mul(h, zT), ldv(c, t + (size_t)k * nt));
+        Limbs9 one261;
+#pragma unroll
+        for (int k = 0; k < NL; k++) one261.d[k] = Fr::ONE[k];
+        acc = mul(h, pow_tab(T, t, one261)); // * z^t
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) sh[k * PT + threadIdx.x] = acc.d[k];
+    __syncthreads();
+    for (uint32_t half = PT / 2; half >= 1; half >>= 1) {
+        if (threadIdx.x < half) {
+            FrM a, b;
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                a.d[k] = sh[k * PT + threadIdx.x];
+                b.d[k] = sh[k * PT + threadIdx.x + half];
+            }
+            FrM sm = tight2<Fr>(add(a, b));
+#pragma unroll
+            for (int k = 0; k < NL; k++) sh[k * PT + threadIdx.x] = sm.d[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        FrM sm;
+#pragma unroll
+        for (int k = 0; k < NL; k++) sm.d[k] = sh[k * PT];
+        stv(A.partial, (size_t)job * 256 + blockIdx.x, sm);
+    }
+}
+__global__ void __launch_bounds__(PT) k_sum_small_batch(EvalBatchArgs A)
+{
+    __shared__ uint32_t sh[NL * PT];
+    const uint32_t job = blockIdx.x, count = A.blocks[job];
+    const uint32_t* partial = A.partial + (size_t)job * 256 * 8;
+    FrM acc = mul(fe_zero<Fr>(), fe_from<Fr>(Fr::ONE));
+    for (uint32_t i = threadIdx.x; i < count; i += PT) acc = tight2<Fr>(add(acc, ldv(partial, i)));
+#pragma unroll
+    for (int k = 0; k < NL; k++) sh[k * PT + threadIdx.x] = acc.d[k];
+    __syncthreads();
+    for (uint32_t half = PT / 2; half >= 1; half >>= 1) {
+        if (threadIdx.x < half) {
+            FrM a, b;
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                a.d[k] = sh[k * PT + threadIdx.x];
+                b.d[k] = sh[k * PT + threadIdx.x + half];
+            }
+            FrM sm = tight2<Fr>(add(a, b));
+#pragma unroll
+            for (int k = 0; k < NL; k++) sh[k * PT + threadIdx.x] = sm.d[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        FrM sm;
+#pragma unroll
+        for (int k = 0; k < NL; k++) sm.d[k] = sh[k * PT];
+        stv(A.result[job], 0, sm);
     }
 }
 
@@ -634,33 +715,27 @@ size_t scan_scratch_bytes(size_t n)
 }
 
 // MODE 0 product scan (z ignored) / MODE 1 Horner suffix sums with multiplier z.  n <= 2^22 (one nested level).
-static int scan_run(int mode, const uint64_t* d_in, uint64_t* d_out, size_t n, bool reverse, bool inclusive, const host::Fr* z, Scratch& S,
-                    hipStream_t st, uint64_t* d_total /* optional: 32-byte device slot receiving the full combination */)
+// Up to two independent scans of the same mode share the launches (ScanJob[2]; the second may have n = 0).
+static void scan_fill(int mode, const ScanJob& J, uint8_t* base, ScanArgs& A, ScanArgs& B)
 {
-    if (n == 0) return BBGPU_OK;
-    if (n > ((size_t)SCAN_BLOCK * SCAN_BLOCK)) {
-        set_error("scan of %zu elements: at most 2^22", n);
-        return BBGPU_ERR_SIZE;
-    }
-    int rc = S.ensure(scan_scratch_bytes(n) + 64);
-    if (rc) return rc;
+    const size_t n = J.n;
     const size_t nt = (n + RUN - 1) / RUN, nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK, nt2 = (nb + RUN - 1) / RUN;
-    uint32_t* tpart = (uint32_t*)S.base;
+    uint32_t* tpart = (uint32_t*)base;
     uint32_t* bpart = tpart + nt * 8;
     uint32_t* bcarry = bpart + nb * 8;
     uint32_t* tpart2 = bcarry + nb * 8;
     uint32_t* bpart2 = tpart2 + nt2 * 8; // one element: the grand total
-    ScanArgs A{};
-    A.in = (const uint32_t*)d_in;
-    A.out = (uint32_t*)d_out;
+    A = ScanArgs{};
+    A.in = (const uint32_t*)J.in;
+    A.out = (uint32_t*)J.out;
     A.tpart = tpart;
     A.bpart = bpart;
     A.bcarry = bcarry;
     A.n = (uint32_t)n;
-    A.reverse = reverse ? 1u : 0u;
-    A.inclusive = inclusive ? 1u : 0u;
+    A.reverse = J.reverse ? 1u : 0u;
+    A.inclusive = J.inclusive ? 1u : 0u;
     A.has_carry = 1;
-    ScanArgs B = A; // the nested scan over the block totals: exclusive, same direction
+    B = A; // the nested scan over the block totals: exclusive, same direction
     B.in = bpart;
     B.out = bcarry;
     B.tpart = tpart2;
@@ -670,33 +745,71 @@ static int scan_run(int mode, const uint64_t* d_in, uint64_t* d_out, size_t n, b
     B.n = (uint32_t)nb;
     B.inclusive = 0;
     if (mode == 1) {
-        host::Fr zr = host::fr_pow(*z, RUN);
+        host::Fr zr = host::fr_pow(J.z, RUN);
         host::Fr p = zr;
         for (int j = 0; j < 8; j++) { A.zpow[j] = host::limbs_m261(p); p = host::fr_sqr(p); }
-        A.zpow[8] = host::limbs_m261(*z);
+        A.zpow[8] = host::limbs_m261(J.z);
         A.zpow[9] = host::limbs_m261(zr);
         // nested level: its "elements" are whole blocks, so its z is z^SCAN_BLOCK
-        host::Fr zb = host::fr_pow(*z, SCAN_BLOCK);
+        host::Fr zb = host::fr_pow(J.z, SCAN_BLOCK);
         host::Fr zbr = host::fr_pow(zb, RUN);
         p = zbr;
         for (int j = 0; j < 8; j++) { B.zpow[j] = host::limbs_m261(p); p = host::fr_sqr(p); }
         B.zpow[8] = host::limbs_m261(zb);
         B.zpow[9] = host::limbs_m261(zbr);
     }
+}
+int scan_pair(int mode, const ScanJob* jobs, int count, Scratch& S, hipStream_t st)
+{
+    if (count < 1 || count > 2) return BBGPU_ERR_ARG;
+    size_t off[3] = { 0, 0, 0 }, nbmax = 0;
+    for (int j = 0; j < count; j++) {
+        if (jobs[j].n > ((size_t)SCAN_BLOCK * SCAN_BLOCK)) {
+            set_error("scan of %zu elements: at most 2^22", jobs[j].n);
+            return BBGPU_ERR_SIZE;
+        }
+        off[j + 1] = off[j] + ((scan_scratch_bytes(jobs[j].n) + 255) & ~(size_t)255);
+        nbmax = std::max(nbmax, (jobs[j].n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    }
+    if (nbmax == 0) return BBGPU_OK;
+    int rc = S.ensure(off[count] + 64);
+    if (rc) return rc;
+    ScanArgs A[2], B[2];
+    A[1] = ScanArgs{};
+    B[1] = ScanArgs{};
+    bool any_out = false;
+    for (int j = 0; j < count; j++) {
+        scan_fill(mode, jobs[j], S.base + off[j], A[j], B[j]);
+        any_out = any_out || jobs[j].out;
+    }
+    ScanArgs A3[2] = { A[0], A[1] };
+    for (int j = 0; j < count; j++)
+        if (!jobs[j].out) A3[j].n = 0;
+    const dim3 g1((uint32_t)nbmax, count), gb(1, count);
     if (mode == 0) {
-        k_scan_phase1<0><<<(uint32_t)nb, SCAN_T, 0, st>>>(A);
-        k_scan_phase1<0><<<1, SCAN_T, 0, st>>>(B);
-        k_scan_phase3<0><<<1, SCAN_T, 0, st>>>(B);
-        if (d_out) k_scan_phase3<0><<<(uint32_t)nb, SCAN_T, 0, st>>>(A);
+        k_scan_phase1<0><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
+        k_scan_phase1<0><<<gb, SCAN_T, 0, st>>>(B[0], B[1]);
+        k_scan_phase3<0><<<gb, SCAN_T, 0, st>>>(B[0], B[1]);
+        if (any_out) k_scan_phase3<0><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
     } else {
-        k_scan_phase1<1><<<(uint32_t)nb, SCAN_T, 0, st>>>(A);
-        k_scan_phase1<1><<<1, SCAN_T, 0, st>>>(B);
-        k_scan_phase3<1><<<1, SCAN_T, 0, st>>>(B);
-        if (d_out) k_scan_phase3<1><<<(uint32_t)nb, SCAN_T, 0, st>>>(A);
+        k_scan_phase1<1><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
+        k_scan_phase1<1><<<gb, SCAN_T, 0, st>>>(B[0], B[1]);
+        k_scan_phase3<1><<<gb, SCAN_T, 0, st>>>(B[0], B[1]);
+        if (any_out) k_scan_phase3<1><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
     }
     HIPCHK(hipGetLastError());
-    if (d_total) HIPCHK(hipMemcpyAsync(d_total, bpart2, 32, hipMemcpyDeviceToDevice, st));
+    for (int j = 0; j < count; j++)
+        if (jobs[j].d_total && jobs[j].n) HIPCHK(hipMemcpyAsync(jobs[j].d_total, B[j].bpart, 32, hipMemcpyDeviceToDevice, st));
     return BBGPU_OK;
+}
+static int scan_run(int mode, const uint64_t* d_in, uint64_t* d_out, size_t n, bool reverse, bool inclusive, const host::Fr* z, Scratch& S,
+                    hipStream_t st, uint64_t* d_total /* optional: 32-byte device slot receiving the full combination */)
+{
+    if (n == 0) return BBGPU_OK;
+    ScanJob J{};
+    J.in = d_in; J.out = d_out; J.n = n; J.reverse = reverse; J.inclusive = inclusive; J.d_total = d_total;
+    if (z) J.z = *z;
+    return scan_pair(mode, &J, 1, S, st);
 }
 
 int product_scan(const uint64_t* d_in, uint64_t* d_out, size_t n, bool reverse, bool inclusive, Scratch& S, hipStream_t st, uint64_t* d_total)
@@ -738,6 +851,34 @@ int evaluate(const uint64_t* d_coeffs, size_t n, const host::Fr& z, host::Fr* ou
     HIPCHK(hipMemcpyAsync(S.h_pinned, d_res, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(out->d, S.h_pinned, 32);
+    return BBGPU_OK;
+}
+
+// up to 8 evaluations (each at z[0] or z[1]) in one pair of launches; results land in the jobs' 32-byte device slots
+int evaluate_batch_to_device(const EvalJob* jobs, int count, const host::Fr z[2], Scratch& S, hipStream_t st)
+{
+    if (count < 1 || count > 8) return BBGPU_ERR_ARG;
+    int rc = S.ensure((size_t)8 * 256 * 32 + 64);
+    if (rc) return rc;
+    EvalBatchArgs A{};
+    A.T[0] = make_powtab(z[0]);
+    A.T[1] = make_powtab(z[1]);
+    A.partial = (uint32_t*)S.base;
+    uint32_t maxb = 1;
+    for (int j = 0; j < count; j++) {
+        const size_t n = jobs[j].n;
+        const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>((n + PT - 1) / PT, 1), 256);
+        A.c[j] = (const uint32_t*)jobs[j].coeffs;
+        A.n[j] = (uint32_t)n;
+        A.blocks[j] = blocks;
+        A.zsel[j] = (uint8_t)(jobs[j].zsel ? 1 : 0);
+        A.zT[j] = host::limbs_m261(host::fr_pow(z[A.zsel[j]], (uint64_t)blocks * PT));
+        A.result[j] = (uint32_t*)jobs[j].d_result;
+        maxb = std::max(maxb, blocks);
+    }
+    k_eval_partial_batch<<<dim3(maxb, count), PT, 0, st>>>(A);
+    k_sum_small_batch<<<count, PT, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
     return BBGPU_OK;
 }
 

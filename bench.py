@@ -86,6 +86,44 @@ def cpu_baseline(table, scalars, expect_xy, ntt_in, ntt_expect):
     return out
 
 
+def plonk_leg(G, args, gates=65536, reps=10):
+    """BASELINE config 5: construct_proof() of the resident prover (bbgpu_plonk_*) on the reference benchmark's add/mul-chain circuit
+    (bench_plonk.cpp:25-37) of 2^16 gates; when the test-only reference build travelled with the repo and the cpu_baseline leg is on,
+    the reference's own prover is timed on the host cores beside it and the two proofs are compared byte for byte."""
+    import re
+    import subprocess
+    from barretenberg_amd.plonk import FR_MODULUS, Prover, bench_circuit, proof_lines, to_montgomery_limbs
+    a0 = 0x0777777788888888555555556666666633333333444444441111111122222222
+    b0 = 0x0ABCDEFABCDEFABC1234123412341234DDDDEEEEFFFF00009999AAAABBBBCCCC
+    secret = 0x0123456789ABCDEF0F1E2D3C4B5A6978FEDCBA98765432100123456789ABCDEF
+    state = bench_circuit(gates, a0, b0).preprocess()
+    srs = G.srs_generate(to_montgomery_limbs([secret % FR_MODULUS])[0], state["n"])
+    P = Prover(G, state, srs)
+    first = P.construct_proof()
+    prep = P.timing()["first_use_preparation_ms"]
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        P.construct_proof()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    out = {"metric": "construct_proof ms, StandardComposer add/mul chain of %d gates, all polynomials resident" % gates, "n": int(state["n"]),
+           "ms": float(np.median(ts)), "ms_min": float(min(ts)), "proofs_per_s": 1e3 / float(np.median(ts)),
+           "circuit_only_preparation_ms": prep, "reference": None}
+    exe = os.path.join(ROOT, "oracle", "_ref", "plonk_cpu")
+    if not args.no_cpu_baseline and os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "transcript.dat")):
+        threads = min(16, os.cpu_count() or 1)
+        r = subprocess.run([exe, "prove", str(gates)], cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        m = re.search(r"construct_proof ([0-9.]+) ms", r.stderr)
+        ref_lines = r.stdout.strip().split("\n")
+        out["reference"] = {"kind": "reference", "cores": threads, "ms": float(m.group(1)) if m else None,
+                            "proof_bit_exact": ref_lines[:26] == proof_lines(state["n"], first)}
+        if m:
+            out["speedup_vs_reference_cpu"] = float(m.group(1)) / out["ms"]
+    P.destroy()
+    G.srs_release(srs)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +132,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=LOG2N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-window-tables", action="store_true", help="disable the pre-shifted SRS window tables")
+    ap.add_argument("--no-plonk", action="store_true", help="skip the BASELINE config 5 leg (resident PLONK prover, 2^16 gates)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
     args = ap.parse_args()
@@ -228,6 +267,11 @@ def main():
     torch.cuda.synchronize()
     ntt_out = d_chk.cpu().numpy().view(np.uint64)
 
+    # ---- BASELINE config 5 (rank 0 only, reported beside the headline): the resident PLONK prover on a 2^16-gate circuit ----------
+    plonk = None
+    if rank == 0 and not args.no_plonk:
+        plonk = plonk_leg(G, args)
+
     if rank == 0:
         alg_bytes = n * (32 + 64) + 96  # every scalar and base point once, one result
         acc_ms = float(stage_pipe[3]) if stage_pipe[3] > 0 else float(stage[3])  # average over the timed region's launches
@@ -273,6 +317,8 @@ def main():
                                  "frac": ntt_bytes / (ntt["fft"]["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                  "kernel": "ntt_pass_kernel x2"}},
         }
+        if plonk is not None:
+            line["plonk"] = plonk
         if not args.no_cpu_baseline:
             # expected NTT output comes from the reference run inside cpu_baseline; pass the GPU's so it can compare
             cb = cpu_baseline(table, scalars, res[:8], ntt_in, ntt_out)

@@ -57,6 +57,9 @@ const char* bbgpu_version(void);
  * `hip_stream` (a hipStream_t, may be NULL for the default stream). */
 int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant);
 int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* constant, void* hip_stream);
+/* `batch` (<= 64) transforms of the same size and kind in one set of launches; transform j occupies
+ * d_coeffs[j * stride_elems .. j * stride_elems + n) (the prover transforms its three wire / sigma polynomials together) */
+int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, int batch, int kind, const uint64_t* constant, void* hip_stream);
 
 /* ---- MSM ---------------------------------------------------------------------------------------------------------
  * The prover passes the same SRS to every MSM (reference_string.cpp:16-35), laid out as the 2n-entry endomorphism
@@ -109,6 +112,13 @@ int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars
 int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                               int window_end, void* hip_stream);
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12]);
+/* Whole-batch entry (the prover commits 3 / 1 / 3 / 2 polynomials per round over the same SRS,
+ * prover.cpp:65-122,650-658): `jobs` (1..4) resident scalar vectors of n scalars each against points [offset, offset + n) of a
+ * table registered WITH window tables, issued as ONE pass through the pipeline -- one bucket set per job in the shared sort /
+ * accumulate / merge / reduction kernels -- so the batch pays one chain of launches and dependent additions, not `jobs`.
+ * bbgpu_msm_g1_batch_wait writes jobs x 12 limbs (normalised).  Uses one of the four tickets. */
+int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_t* const* d_scalars, int jobs, size_t n, void* hip_stream);
+int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out);
 /* out = sum of `count` normalised/Jacobian points (infinity flags honoured), normalised.  Host arithmetic. */
 int bbgpu_g1_sum(const uint64_t* points12, size_t count, uint64_t out[12]);
 

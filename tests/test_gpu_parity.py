@@ -273,6 +273,39 @@ def test_msm_additivity_large(gpu, oracle):
         gpu.srs_release(h)
 
 
+def test_msm_device_batch(gpu, oracle, msm_small):
+    """whole-batch entry: up to four scalar vectors over the same points in one pass = the single MSMs, including
+    an all-zero vector, a skewed one, and sub-ranges of the registered table"""
+    import torch
+    from barretenberg_amd import BbGpuError
+    g, srs, table, scalars = msm_small
+    h = gpu.srs_register(table)
+    one = oracle.to_mont(FR, np.array([1, 0, 0, 0], dtype=np.uint64))
+    for n in (16, 1000, 4096, 65536):
+        sets = [scalars[:n], scalars[::-1][:n].copy(), np.zeros((n, 4), dtype=np.uint64), np.tile(one, (n, 1))]
+        dev = [torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda() for a in sets]
+        single = [gpu.msm_device(h, d.data_ptr(), n) for d in dev]
+        assert oracle.is_infinity(single[2]) and not oracle.is_infinity(single[0])
+        for jobs in (1, 2, 3, 4):
+            try:
+                t = gpu.msm_device_batch_async(h, [d.data_ptr() for d in dev[:jobs]], n)
+            except BbGpuError:
+                assert jobs > 1  # no window tables on this SRS (the no-tables parametrisation): refused, callers fall back
+                continue
+            got = gpu.msm_batch_wait(t)
+            for j in range(jobs):
+                assert np.array_equal(got[j], single[j]), (n, jobs, j)
+    # a sub-range of the table
+    n, off = 3000, 777
+    d = torch.from_numpy(scalars[:n].view(np.int64)).cuda()
+    want = gpu.msm_device(h, d.data_ptr(), n, offset=off)
+    try:
+        got = gpu.msm_batch_wait(gpu.msm_device_batch_async(h, [d.data_ptr(), d.data_ptr()], n, offset=off))
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+    except BbGpuError:
+        pass
+
+
 def test_msm_async_pipeline(gpu, oracle, msm_small):
     """two MSMs in flight (bbgpu_msm_g1_device_async / _wait): results independent of the overlap"""
     import torch
