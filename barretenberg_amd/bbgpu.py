@@ -33,7 +33,7 @@ NTT_KINDS = {
 
 C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
-    "bbgpu_ntt_device", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
+    "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
     "bbgpu_srs_num_windows", "bbgpu_msm_g1",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
@@ -86,6 +86,7 @@ class BbGpu:
         L.bbgpu_version.restype = C.c_char_p
         L.bbgpu_ntt.argtypes = [u64p, C.c_size_t, C.c_int, u64p]
         L.bbgpu_ntt_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, u64p, C.c_void_p]
+        L.bbgpu_ntt_device_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
         L.bbgpu_srs_register.argtypes = [u64p, C.c_size_t]
         L.bbgpu_srs_generate.argtypes = [u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1.argtypes = [u64p, u64p, C.c_size_t, u64p]
@@ -146,6 +147,12 @@ class BbGpu:
         kind = NTT_KINDS[kind] if isinstance(kind, str) else kind
         cp = _ptr(np.ascontiguousarray(constant, dtype=np.uint64)) if constant is not None else None
         self._chk(self.lib.bbgpu_ntt_device(C.c_void_p(d_ptr), n, kind, cp, C.c_void_p(stream or 0)))
+
+    def ntt_device_batch(self, d_ptr, n, batch, kind, constant=None, stride=None, stream=None):
+        """`batch` transforms of consecutive n-element vectors (stride elements apart) in one set of launches"""
+        kind = NTT_KINDS[kind] if isinstance(kind, str) else kind
+        cp = _ptr(np.ascontiguousarray(constant, dtype=np.uint64)) if constant is not None else None
+        self._chk(self.lib.bbgpu_ntt_device_batch(C.c_void_p(d_ptr), n, stride or n, batch, kind, cp, C.c_void_p(stream or 0)))
 
     # ---- the O(n) helpers between transforms and commitments, on device-resident vectors (raw device pointers) -----
     def evaluate_device(self, d_coeffs, n, z, stream=None):

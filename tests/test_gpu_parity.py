@@ -35,6 +35,23 @@ def test_ntt_vs_oracle_all_kinds(gpu, oracle, const, log2n):
         assert np.array_equal(got, want), (log2n, kind)
 
 
+@pytest.mark.parametrize("log2n", [3, 10, 12, 14])
+def test_ntt_batched_launch_equals_single(gpu, oracle, const, log2n):
+    """bbgpu_ntt_device_batch: several transforms per launch (single-pass and two-pass sizes, padded stride) = the single ones"""
+    import torch
+    n, batch, stride = 1 << log2n, 5, (1 << log2n) + 24
+    co = noncanonical(oracle.random_scalars(NTT_SEED + 77 + log2n, batch * stride), FR_MODULUS)
+    for kind in ("fft", "coset_fft", "ifft_with_constant", "coset_ifft", "coset_fft_with_constant"):
+        d = torch.from_numpy(co.view(np.int64)).cuda()
+        gpu.ntt_device_batch(d.data_ptr(), n, batch, kind, const, stride=stride)
+        torch.cuda.synchronize()
+        got = d.cpu().numpy().view(np.uint64)
+        for j in range(batch):
+            want = oracle.ntt(co[j * stride:j * stride + n], kind, const)
+            assert np.array_equal(got[j * stride:j * stride + n], want), (log2n, kind, j)
+            assert np.array_equal(got[j * stride + n:(j + 1) * stride], co[j * stride + n:(j + 1) * stride])  # the gap is untouched
+
+
 def test_ntt_golden_small(gpu, golden):
     g = golden("ntt.json")
     c = limbs(g["constant"])
