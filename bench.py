@@ -269,7 +269,7 @@ def main():
 
     # ---- BASELINE config 5 (rank 0 only, reported beside the headline): the resident PLONK prover on a 2^16-gate circuit ----------
     plonk = None
-    if rank == 0 and not args.no_plonk:
+    if rank == 0 and world == 1 and not args.no_plonk:  # single-GPU leg; the N > 1 runs measure the window-sharded MSM only
         plonk = plonk_leg(G, args)
 
     if rank == 0:

@@ -34,7 +34,7 @@ def test_composer_mirror_full_state_32(trace):
             assert [["%016x" % int(x) for x in row] for row in st[k]] == v, k
 
 
-@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536])
+@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536, 262144])
 def test_composer_mirror_digests(trace, gates):
     st = bench_circuit(gates, *witnesses(trace)).preprocess()
     want = trace["input_digests"][str(gates)]
@@ -44,7 +44,7 @@ def test_composer_mirror_digests(trace, gates):
             assert hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() == d, k
 
 
-@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536])
+@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536, 262144, 1048576])
 def test_transcript_challenges_match_reference(golden, trace, gates):
     """challenge.hpp:64-112 restated in plonk.hip (host code): gamma, beta, alpha, z recomputed from the reference's golden proof"""
     lines = golden("plonk_proofs.json")["proofs"][str(gates)]

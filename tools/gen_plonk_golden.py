@@ -6,6 +6,10 @@ unmodified composer / prover / verifier compiled in place by oracle/Makefile; dr
                                    digests of the waffle::Prover input state (`plonk_cpu dump`) per circuit size, plus the
                                    complete input state of the 32-gate circuit
 Run in the build container (needs /root/reference at oracle build time):  python tools/gen_plonk_golden.py
+Circuits above 2^16 gates need a longer SRS than the 65,536-point oracle/_ref/transcript.dat: write one with
+`cd $DIR && mkdir -p oracle/_ref && plonk_cpu transcript oracle/_ref/transcript.dat 1048576` (1 min) and pass BBGPU_BIG_SRS_DIR=$DIR;
+the reference binary reads its transcript relative to the working directory.  Their proofs are appended to
+tests/golden/plonk_proofs.json as well (the 32..2^16 entries of that file come from `plonk_cpu prove`).
 """
 import hashlib
 import json
@@ -42,13 +46,18 @@ def main():
            "witness_a0": "0777777788888888555555556666666633333333444444441111111122222222",
            "witness_b0": "0abcdefabcdefabc1234123412341234ddddeeeeffff00009999aaaabbbbcccc",
            "challenges": {}, "input_digests": {}}
-    for gates in (32, 1024, 16384, 65536):
-        r = subprocess.run([EXE, "trace", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True)
+    big = os.environ.get("BBGPU_BIG_SRS_DIR")
+    proofs_path = os.path.join(ROOT, "tests", "golden", "plonk_proofs.json")
+    proofs = json.load(open(proofs_path))
+    for gates in (32, 1024, 16384, 65536) + ((262144, 1048576) if big else ()):
+        r = subprocess.run([EXE, "trace", str(gates)], cwd=big if gates > 65536 else ROOT, capture_output=True, text=True, check=True)
         lines = r.stdout.strip().split("\n")
+        if gates > 65536:
+            proofs["proofs"][str(gates)] = [ln for ln in lines if ln.split()[0] not in ("beta", "gamma", "alpha", "z", "nu")]
         ch = {ln.split()[0]: ln.split()[1] for ln in lines if ln.split()[0] in ("beta", "gamma", "alpha", "z", "nu")}
         out["challenges"][str(gates)] = ch
         path = "/tmp/plonk_dump_%d.bin" % gates
-        subprocess.run([EXE, "dump", str(gates), path], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+        subprocess.run([EXE, "dump", str(gates), path], cwd=big if gates > 65536 else ROOT, check=True, stdout=subprocess.DEVNULL)
         st = load_dump(path)
         out["input_digests"][str(gates)] = {k: hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() for k in FIELDS64 + MAPS + SELECTORS}
         out["input_digests"][str(gates)]["n"] = st["n"]
@@ -56,6 +65,14 @@ def main():
             out["input_state_32"] = {k: [["%016x" % int(v) for v in row] for row in st[k]] for k in FIELDS64 + SELECTORS}
             out["input_state_32"].update({k: [int(v) for v in st[k]] for k in MAPS})
         os.remove(path)
+    if not big:  # keep the large-circuit entries of an earlier run
+        old = json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_trace.json")))
+        for key in ("challenges", "input_digests"):
+            for g, v in old.get(key, {}).items():
+                out[key].setdefault(g, v)
+    else:
+        with open(proofs_path, "w") as fh:
+            json.dump(proofs, fh, indent=0)
     with open(os.path.join(ROOT, "tests", "golden", "plonk_trace.json"), "w") as fh:
         json.dump(out, fh, indent=0)
     print("wrote tests/golden/plonk_trace.json")
