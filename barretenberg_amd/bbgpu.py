@@ -34,7 +34,7 @@ NTT_KINDS = {
 C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
     "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
-    "bbgpu_srs_num_windows", "bbgpu_msm_g1",
+    "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_msm_g1",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing",
@@ -200,6 +200,13 @@ class BbGpu:
         h = self._chk(self.lib.bbgpu_srs_generate(_ptr(np.ascontiguousarray(x_mont, dtype=np.uint64)), n,
                                                   _ptr(table) if want_host_table else None))
         return (h, table) if want_host_table else h
+
+    def read_transcript(self, path, degree):
+        """io::read_transcript (io.hpp:159-181), G1 part -> the (2 * degree, 8) endo table the reference's ReferenceString holds"""
+        self.lib.bbgpu_transcript_read_g1.argtypes = [C.c_char_p, C.c_size_t, u64p]
+        table = np.zeros((2 * degree, 8), dtype=np.uint64)
+        self._chk(self.lib.bbgpu_transcript_read_g1(path.encode(), degree, _ptr(table)))
+        return table
 
     def srs_release(self, handle):
         self._chk(self.lib.bbgpu_srs_release(handle))

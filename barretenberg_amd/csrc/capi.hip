@@ -457,6 +457,69 @@ int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_tab
     return add_srs(host_endo_table_out, n, d);
 }
 
+// io.hpp:36-182 restated for the G1 part: 28-byte manifest of seven big-endian uint32 (fields 5 = num_g1_points), then points as
+// x, y, each four 64-bit limbs least-significant limb first, every limb big-endian, NOT in Montgomery form; file point k is
+// x^(k+1) G and monomials[0] is the generator (read_transcript :159-181).  Fills the complete 2n-entry endomorphism table of
+// generate_pippenger_point_table (scalar_multiplication.cpp:131-140): entry 2i = P_i, entry 2i+1 = (beta x_i, -y_i).  Host only.
+int bbgpu_transcript_read_g1(const char* path, size_t degree, uint64_t* points_endo_table_out)
+{
+    if (!path || !points_endo_table_out || degree == 0) return BBGPU_ERR_ARG;
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        set_error("cannot open transcript %s", path);
+        return BBGPU_ERR_ARG;
+    }
+    unsigned char man[28];
+    if (fread(man, 1, 28, f) != 28) {
+        fclose(f);
+        set_error("transcript %s: short manifest", path);
+        return BBGPU_ERR_SIZE;
+    }
+    auto be32 = [&](int i) { return ((uint32_t)man[4 * i] << 24) | ((uint32_t)man[4 * i + 1] << 16) | ((uint32_t)man[4 * i + 2] << 8) | man[4 * i + 3]; };
+    const uint32_t num_g1 = be32(4);
+    if ((size_t)num_g1 + 1 < degree) {
+        fclose(f);
+        set_error("transcript %s holds %u G1 points, %zu needed", path, num_g1, degree - 1);
+        return BBGPU_ERR_SIZE;
+    }
+    const host::Fq rsq = { { 0xF32CFC5B538AFA89ULL, 0xB5E71911D44501FBULL, 0x47AB1EFF0A417FF6ULL, 0x06D89F71CAB8351FULL } }; // 2^512 mod q (fq.hpp:48-51)
+    const host::Fq beta = { { 0x71930c11d782e155ULL, 0xa6bb947cffbe3323ULL, 0xaa303344d4741444ULL, 0x2c3b3f0d26594943ULL } }; // fq.hpp:53-56 (Montgomery)
+    const host::Fq zero = { { 0, 0, 0, 0 } };
+    auto put = [&](size_t i, const host::Fq& x, const host::Fq& y) {
+        uint64_t* e = points_endo_table_out + i * 16;
+        memcpy(e, x.d, 32);
+        memcpy(e + 4, y.d, 32);
+        const host::Fq bx = host::fq_mul(x, beta), ny = host::fq_sub(zero, y);
+        memcpy(e + 8, bx.d, 32);
+        memcpy(e + 12, ny.d, 32);
+    };
+    host::Fq two = host::fq_add(host::FQ_ONE, host::FQ_ONE);
+    put(0, host::FQ_ONE, two); // g1::affine_one = (1, 2) (g1.hpp:14-16)
+    std::vector<unsigned char> buf(64 * 4096);
+    size_t done = 1;
+    while (done < degree) {
+        const size_t chunk = std::min<size_t>(4096, degree - done);
+        if (fread(buf.data(), 64, chunk, f) != chunk) {
+            fclose(f);
+            set_error("transcript %s: short read", path);
+            return BBGPU_ERR_SIZE;
+        }
+        for (size_t k = 0; k < chunk; k++) {
+            host::Fq c[2];
+            for (int xy = 0; xy < 2; xy++)
+                for (int l = 0; l < 4; l++) {
+                    uint64_t v = 0;
+                    for (int b = 0; b < 8; b++) v = (v << 8) | buf[k * 64 + xy * 32 + l * 8 + b];
+                    c[xy].d[l] = v;
+                }
+            put(done + k, host::fq_mul(c[0], rsq), host::fq_mul(c[1], rsq));
+        }
+        done += chunk;
+    }
+    fclose(f);
+    return BBGPU_OK;
+}
+
 int bbgpu_srs_release(int handle)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);

@@ -78,6 +78,11 @@ void bbgpu_set_precompute(int enabled);
  * shard windows over ranks: a table carries the window size it was built for) */
 int bbgpu_srs_num_windows(int srs_handle, size_t n);
 int bbgpu_srs_release(int handle);
+/* io::read_transcript, G1 part (io/io.hpp:36-182): reads `degree - 1` points of an ignition-format transcript file
+ * (srs_db/transcript.dat) behind the generator and writes the 2 * degree entry endomorphism table of
+ * generate_pippenger_point_table -- the `monomials` array of ReferenceString (reference_string.cpp:16-35) -- ready for
+ * bbgpu_srs_register.  Host code; needs no GPU. */
+int bbgpu_transcript_read_g1(const char* path, size_t degree, uint64_t* points_endo_table_out);
 /* device-side generation of the synthetic SRS x^i * G, i < n, straight into a resident table; optionally also written
  * back to the host as the reference-format 2n endo table (may be NULL).  Stands in for the missing srs_db/transcript.dat */
 int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out);

@@ -218,3 +218,34 @@ def test_resident_prover_rejects_bad_input(gpu, srs65536):
         Prover(gpu, bad, srs65536)
     with pytest.raises(BbGpuError):
         Prover(gpu, state, 12345)
+
+
+def test_resident_prover_on_a_transcript_file(gpu, golden, tmp_path):
+    """the SRS path a real deployment takes: an ignition-format transcript file (io.hpp:36-182) read by bbgpu_transcript_read_g1,
+    registered (uploaded + window tables) and used by the resident prover -- same proof bytes as with the device-generated SRS.
+    The file is written here from the synthetic SRS in the format's own terms (limb 0 first, limbs big-endian, plain form)."""
+    from barretenberg_amd.plonk import Prover, bench_circuit, proof_lines
+    from oracle.pyoracle import FQ, Oracle
+    O = Oracle()
+    n = 1024
+    srs = O.make_srs(P.mont([SECRET_RAW % FR_MODULUS])[0], n)
+    path = str(tmp_path / "transcript.dat")
+    with open(path, "wb") as fh:
+        for v in (0, 1, n - 1, 2, n - 1, 2, 0):
+            fh.write(int(v).to_bytes(4, "big"))
+        for i in range(1, n):
+            for c in (srs[i][0:4], srs[i][4:8]):
+                for limb in O.from_mont(FQ, c):
+                    fh.write(int(limb).to_bytes(8, "big"))
+        fh.write(bytes(256 + 64))
+    table = gpu.read_transcript(path, n)
+    h = gpu.srs_register(table)
+    tr = golden("plonk_trace.json")
+    for gates in (32, 1024):
+        state = bench_circuit(gates, int(tr["witness_a0"], 16), int(tr["witness_b0"], 16)).preprocess()
+        prover = Prover(gpu, state, h)
+        try:
+            assert proof_lines(state["n"], prover.construct_proof()) == golden("plonk_proofs.json")["proofs"][str(gates)][:26]
+        finally:
+            prover.destroy()
+    gpu.srs_release(h)

@@ -116,3 +116,40 @@ def test_shim_defines_reference_symbols(lib):
                          capture_output=True, text=True, check=True).stdout
     defined = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"}
     assert set(REFERENCE_SYMBOLS) <= defined
+
+
+def test_transcript_reader_matches_reference_format(tmp_path):
+    """bbgpu_transcript_read_g1 (io.hpp:36-182 restated, host code) on a transcript written in the reference's format: the table equals
+    generator + x^k G in Montgomery form with the endomorphism partners -- the array the reference's ReferenceString holds.
+    The file comes from the reference's own code path when its test-only build is present (oracle/_ref/plonk_cpu transcript), and is
+    always cross-checked against a writer restated here from the format description."""
+    import subprocess
+    from barretenberg_amd import BbGpu
+    from oracle.pyoracle import FQ, Oracle, from_int
+    O = Oracle()
+    G = BbGpu(init=False)
+    n = 64
+    secret = 0x0123456789ABCDEF0F1E2D3C4B5A6978FEDCBA98765432100123456789ABCDEF
+    x_mont = O.to_mont(1, from_int(secret))
+    srs = O.make_srs(x_mont, n)  # x^i G, i < n, Montgomery
+    want = O.point_table(srs)
+    # writer restated from the format: manifest of seven big-endian u32, then x, y as 4 limbs (limb 0 first), each limb big-endian, plain form
+    path = str(tmp_path / "t.dat")
+    with open(path, "wb") as fh:
+        for v in (0, 1, n - 1, 2, n - 1, 2, 0):
+            fh.write(int(v).to_bytes(4, "big"))
+        for i in range(1, n):
+            for c in (srs[i][0:4], srs[i][4:8]):
+                plain = O.from_mont(FQ, c)
+                for limb in plain:
+                    fh.write(int(limb).to_bytes(8, "big"))
+        fh.write(bytes(256 + 64))
+    got = G.read_transcript(path, n)
+    assert np.array_equal(got, want)
+    exe = os.path.join(ROOT, "oracle", "_ref", "plonk_cpu")
+    if os.path.exists(exe):
+        ref_path = str(tmp_path / "ref.dat")
+        subprocess.run([exe, "transcript", ref_path, str(n - 1)], check=True, stdout=subprocess.DEVNULL)
+        assert np.array_equal(G.read_transcript(ref_path, n), want)
+    with pytest.raises(Exception):
+        G.read_transcript(path, n + 5)  # more points than the file holds
