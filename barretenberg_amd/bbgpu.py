@@ -42,6 +42,8 @@ C_ABI_SYMBOLS = [
     "bbgpu_fr_evaluate_device", "bbgpu_fr_batch_invert_device", "bbgpu_fr_product_scan_device", "bbgpu_fr_mul_device",
     "bbgpu_kate_opening_device", "bbgpu_lagrange_l1_fft_device", "bbgpu_divide_by_pseudo_vanishing_device",
     "bbgpu_permutation_lagrange_base_device",
+    "bbgpu_fr_evaluate", "bbgpu_kate_opening", "bbgpu_lagrange_l1_fft", "bbgpu_divide_by_pseudo_vanishing", "bbgpu_lagrange_evaluations",
+    "bbgpu_generate_point_table",
     "bbgpu_plonk_prover_create", "bbgpu_plonk_prover_set_witness", "bbgpu_plonk_construct_proof", "bbgpu_plonk_last_challenges",
     "bbgpu_plonk_last_timing", "bbgpu_plonk_prover_destroy", "bbgpu_plonk_challenges_from_proof",
 ]

@@ -429,6 +429,105 @@ int bbgpu_permutation_lagrange_base_device(uint64_t* d_out, const uint32_t* d_ma
     return poly::sigma_from_mapping(d_out, d_mapping, g_ctx.d_poly_tmp, n, st);
 }
 
+/* ---- the same helpers on host buffers (what the C++ shim forwards the reference's co-resident TU functions to) ---- */
+static int stage_in(const uint64_t* host, size_t n)
+{
+    int rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
+    if (rc) return rc;
+    CHK(hipMemcpyAsync(g_ctx.d_stage, host, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+    return BBGPU_OK;
+}
+static int stage_out(uint64_t* host, const uint64_t* dev, size_t n)
+{
+    CHK(hipMemcpyAsync(host, dev, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
+    CHK(hipStreamSynchronize(g_ctx.stream));
+    return BBGPU_OK;
+}
+
+int bbgpu_fr_evaluate(const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((!coeffs && n) || !z || !out) return BBGPU_ERR_ARG;
+    if ((rc = stage_in(coeffs, n)) != BBGPU_OK) return rc;
+    return bbgpu_fr_evaluate_device(g_ctx.d_stage, n, z, out, g_ctx.stream);
+}
+
+int bbgpu_kate_opening(const uint64_t* src, uint64_t* dest, size_t n, const uint64_t z[4], uint64_t f_of_z[4])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (((!src || !dest) && n) || !z) return BBGPU_ERR_ARG;
+    if ((rc = stage_in(src, n)) != BBGPU_OK) return rc;
+    if ((rc = grow(&g_ctx.d_stage2, &g_ctx.stage2_cap, n * 32)) != BBGPU_OK) return rc;
+    if ((rc = bbgpu_kate_opening_device(g_ctx.d_stage, g_ctx.d_stage2, n, z, f_of_z, g_ctx.stream)) != BBGPU_OK) return rc;
+    return stage_out(dest, g_ctx.d_stage2, n);
+}
+
+int bbgpu_lagrange_l1_fft(uint64_t* l_1, size_t n_src, size_t n_target)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!l_1) return BBGPU_ERR_ARG;
+    if ((rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n_target * 32)) != BBGPU_OK) return rc;
+    if ((rc = bbgpu_lagrange_l1_fft_device(g_ctx.d_stage, n_src, n_target, g_ctx.stream)) != BBGPU_OK) return rc;
+    return stage_out(l_1, g_ctx.d_stage, n_target);
+}
+
+int bbgpu_divide_by_pseudo_vanishing(uint64_t* coeffs, size_t n_src, size_t n_target)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!coeffs) return BBGPU_ERR_ARG;
+    if ((rc = stage_in(coeffs, n_target)) != BBGPU_OK) return rc;
+    if ((rc = bbgpu_divide_by_pseudo_vanishing_device(g_ctx.d_stage, n_src, n_target, g_ctx.stream)) != BBGPU_OK) return rc;
+    return stage_out(coeffs, g_ctx.d_stage, n_target);
+}
+
+// polynomial_arithmetic::get_lagrange_evaluations (polynomial_arithmetic.cpp:594-626): {Z_H*(z), L_1(z), L_{n-1}(z)}; host arithmetic
+int bbgpu_lagrange_evaluations(const uint64_t z[4], size_t n, uint64_t out[12])
+{
+    const int lg = log2_exact(n);
+    if (!z || !out || lg < 1) return BBGPU_ERR_ARG;
+    const host::Fr zc = load_fr(z), one = host::fr_one(), root = host::fr_root_of_unity(lg), root_inv = host::fr_inv(root);
+    host::Fr zp = zc;
+    for (int i = 0; i < lg; i++) zp = host::fr_sqr(zp);
+    const host::Fr numerator = host::fr_sub(zp, one);
+    const host::Fr d0 = host::fr_inv(host::fr_sub(zc, root_inv)), d1 = host::fr_inv(host::fr_sub(zc, one));
+    const host::Fr d2 = host::fr_inv(host::fr_sub(host::fr_mul(host::fr_mul(zc, root), root), one));
+    const host::Fr scaled = host::fr_mul(numerator, host::fr_inv(host::fr_from_u64((uint64_t)n)));
+    const host::Fr v = host::fr_mul(numerator, d0), l1 = host::fr_mul(scaled, d1), ln = host::fr_mul(scaled, d2);
+    memcpy(out, v.d, 32);
+    memcpy(out + 4, l1.d, 32);
+    memcpy(out + 8, ln.d, 32);
+    return BBGPU_OK;
+}
+
+// scalar_multiplication::generate_pippenger_point_table (scalar_multiplication.cpp:131-140): table[2i] = P_i, table[2i+1] = (beta x_i, -y_i),
+// filled from the back so that `points` may alias `table`.  Host arithmetic (once per SRS).
+int bbgpu_generate_point_table(const uint64_t* points, uint64_t* table, size_t n)
+{
+    if ((!points || !table) && n) return BBGPU_ERR_ARG;
+    const host::Fq beta = { { 0x71930c11d782e155ULL, 0xa6bb947cffbe3323ULL, 0xaa303344d4741444ULL, 0x2c3b3f0d26594943ULL } }; // fq.hpp:53-56
+    const host::Fq zero = { { 0, 0, 0, 0 } };
+    for (size_t i = n; i-- > 0;) {
+        host::Fq x, y;
+        memcpy(x.d, points + i * 8, 32);
+        memcpy(y.d, points + i * 8 + 4, 32);
+        const host::Fq bx = host::fq_mul(x, beta), ny = host::fq_sub(zero, y);
+        uint64_t* e = table + i * 16;
+        memcpy(e + 8, bx.d, 32);
+        memcpy(e + 12, ny.d, 32);
+        memcpy(e, x.d, 32);
+        memcpy(e + 4, y.d, 32);
+    }
+    return BBGPU_OK;
+}
+
 /* ---- SRS ---- */
 int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n)
 {

@@ -67,6 +67,7 @@ struct multiplication_state {
 };
 g1::element pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width);
 void batched_scalar_multiplications(multiplication_state* mul_state, size_t num_batches);
+void generate_pippenger_point_table(g1::affine_element* points, g1::affine_element* table, size_t num_points);
 } // namespace scalar_multiplication
 
 namespace polynomial_arithmetic {
@@ -77,6 +78,19 @@ void coset_ifft(fr::field_t* coeffs, const evaluation_domain& domain);
 void fft_with_constant(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& value);
 void ifft_with_constant(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& value);
 void coset_fft_with_constant(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& constant);
+// co-resident functions of the same translation unit (polynomial_arithmetic.hpp:14-61) that the PLONK stack calls
+struct lagrange_evaluations {
+    fr::field_t vanishing_poly;
+    fr::field_t l_1;
+    fr::field_t l_n_minus_1;
+};
+fr::field_t evaluate(const fr::field_t* coeffs, const fr::field_t& z, const size_t n);
+void copy_polynomial(fr::field_t* src, fr::field_t* dest, size_t num_src_coefficients, size_t num_target_coefficients);
+void compute_lagrange_polynomial_fft(fr::field_t* l_1_coefficients, const evaluation_domain& src_domain, const evaluation_domain& target_domain);
+void divide_by_pseudo_vanishing_polynomial(fr::field_t* coeffs, const evaluation_domain& src_domain, const evaluation_domain& target_domain);
+fr::field_t compute_kate_opening_coefficients(const fr::field_t* src, fr::field_t* dest, const fr::field_t& z, const size_t n);
+lagrange_evaluations get_lagrange_evaluations(const fr::field_t& z, const evaluation_domain& domain);
+void compress_fft(const fr::field_t* src, fr::field_t* dest, const size_t current_size, const size_t compress_factor);
 } // namespace polynomial_arithmetic
 
 // layout probes (measured against the reference headers with sizeof/offsetof)

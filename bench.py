@@ -162,7 +162,8 @@ def main():
 
     # ---- synthetic inputs, identical on every rank, resident in HBM before any timed region -------------------------
     x_secret = random_field_elements(1, 0x5EED)[0]
-    want_table = (rank == 0 and not args.no_cpu_baseline)
+    cpu_leg = (rank == 0 and world == 1 and not args.no_cpu_baseline)  # the CPU reference is timed at N = 1 only
+    want_table = cpu_leg
     if want_table:
         srs, table = G.srs_generate(x_secret, n, want_host_table=True)
     else:
@@ -319,7 +320,7 @@ def main():
         }
         if plonk is not None:
             line["plonk"] = plonk
-        if not args.no_cpu_baseline:
+        if cpu_leg:
             # expected NTT output comes from the reference run inside cpu_baseline; pass the GPU's so it can compare
             cb = cpu_baseline(table, scalars, res[:8], ntt_in, ntt_out)
             line["cpu_baseline"] = cb

@@ -150,6 +150,17 @@ int bbgpu_divide_by_pseudo_vanishing_device(uint64_t* d_coeffs, size_t n_src, si
 /* waffle::compute_permutation_lagrange_base_single(output, permutation, small_domain) (permutation.hpp:15-87) */
 int bbgpu_permutation_lagrange_base_device(uint64_t* d_out, const uint32_t* d_mapping, size_t n, void* hip_stream);
 
+/* The same on host buffers (copied to the device and back): what the C++ shim forwards the co-resident functions of the replaced
+ * translation unit to, so that polynomial_arithmetic.o / scalar_multiplication.o can be left out of the link altogether. */
+int bbgpu_fr_evaluate(const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4]);
+int bbgpu_kate_opening(const uint64_t* src, uint64_t* dest, size_t n, const uint64_t z[4], uint64_t f_of_z[4]);
+int bbgpu_lagrange_l1_fft(uint64_t* l_1, size_t n_src, size_t n_target);
+int bbgpu_divide_by_pseudo_vanishing(uint64_t* coeffs, size_t n_src, size_t n_target);
+/* polynomial_arithmetic::get_lagrange_evaluations(z, domain) (:594-626): out = {Z_H*(z), L_1(z), L_{n-1}(z)}; host arithmetic */
+int bbgpu_lagrange_evaluations(const uint64_t z[4], size_t n, uint64_t out[12]);
+/* scalar_multiplication::generate_pippenger_point_table(points, table, n) (scalar_multiplication.cpp:131-140); points may alias table */
+int bbgpu_generate_point_table(const uint64_t* points, uint64_t* table, size_t n);
+
 /* ---- resident PLONK prover (BASELINE config 5) ------------------------------------------------------
  * waffle::Prover for the standard arithmetic circuit with every polynomial resident in HBM.  The circuit description is
  * the state StandardComposer::preprocess() hands the reference's Prover (standard_composer.cpp:163-220, prover.hpp:44-59,

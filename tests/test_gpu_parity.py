@@ -378,19 +378,23 @@ def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
 
 
 # ------------------------------------------------------------------ config 5: the reference prover on the GPU ----------
+@pytest.mark.parametrize("build", ["plonk_gpu", "plonk_gpu_full"])
 @pytest.mark.parametrize("gates", [32, 1024, 16384, 65536])
-def test_reference_prover_runs_on_gpu_bit_exact(golden, gates):
+def test_reference_prover_runs_on_gpu_bit_exact(golden, gates, build):
     """BASELINE config 5.  oracle/_ref/plonk_gpu is the reference's UNMODIFIED StandardComposer -> waffle::Prover -> Verifier,
     compiled in the build container from the reference sources where they lie, with pippenger / batched_scalar_multiplications /
     the fft family resolved by barretenberg_amd/libbbshim.so -> libbbgpu.so (the INTEGRATION.md link recipe).  Its proof must be
-    byte-identical to the one the all-CPU reference build produced for the same circuit and SRS, and must verify."""
+    byte-identical to the one the all-CPU reference build produced for the same circuit and SRS, and must verify.
+    `plonk_gpu_full` goes further: scalar_multiplication.o and polynomial_arithmetic.o are left out of the link altogether and the shim
+    supplies every function the PLONK stack needs from them (evaluate, compute_kate_opening_coefficients, compute_lagrange_polynomial_fft,
+    divide_by_pseudo_vanishing_polynomial, get_lagrange_evaluations, generate_pippenger_point_table besides the nine hot-path entries)."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "oracle", "_ref", "plonk_gpu")
+    exe = os.path.join(root, "oracle", "_ref", build)
     srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
     if not (os.path.exists(exe) and os.path.exists(srs)):
-        pytest.skip("oracle/_ref/plonk_gpu not built (needs /root/reference at build time)")
+        pytest.skip("oracle/_ref/%s not built (needs /root/reference at build time)" % build)
     env = dict(os.environ, OMP_NUM_THREADS="16")  # the prover's own CPU loops: do not spawn one thread per host core of the box
     r = subprocess.run([exe, "prove", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
