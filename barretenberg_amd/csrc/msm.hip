@@ -476,8 +476,12 @@ constexpr int RAW_WORDS = 4 * NL; // 36 words per partial: lazy limbs, no canoni
 
 __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ gstart, uint32_t* __restrict__ partials,
-                                                                   uint32_t total_buckets, uint32_t ch)
+                                                                   uint32_t total_buckets, uint32_t ch, uint32_t prio)
 {
+    // wave priority above the memory-bound sort kernels of the NEXT MSM that share the CUs in the two-deep pipeline (they have
+    // a whole accumulation of slack), below the latency-bound tail kernels of the previous one (s_setprio 3)
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = gstart[total_buckets];
     const uint32_t p0 = t * ch;
@@ -534,7 +538,46 @@ __device__ __forceinline__ Xyzz shfl_down_xyzz(const Xyzz& p, uint32_t off)
     }
     return r;
 }
-__global__ void __launch_bounds__(MSM_THREADS) msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+// Workgroup tree sum over up to 256 XYZZ points held one per lane (raw lazy limbs staged through LDS, structure of arrays, only
+// the upper half of each level is stored: 128 x 144 B = 18 KiB): the dependent chain is log2(T) additions with no launch gaps.
+// Result in lane 0.  Measured alternatives: a ds_bpermute shuffle tree (576 B of LDS) is 40-60 % slower per level (36 permutes
+// per point and level); staging all 256 lanes needed 36 KiB, which beside three resident accumulation workgroups (3 x 41 KiB
+// of the CU's 160 KiB) only fits when the free LDS happens to be contiguous.
+// The tail kernels are held to 128 VGPRs (amdgpu_waves_per_eu(4, 4), ~32 registers spilled): at the 143 they would otherwise
+// take, their waves do not fit beside the three 128-VGPR accumulation waves per SIMD of the next MSM and the whole tail queued
+// behind it (rocprof timeline: merge 0.5 ms and heavy-merge 0.58 ms in the two-deep pipeline against 0.05 ms alone).
+constexpr int FOLD_T = 256;
+constexpr int FOLD_LDS_WORDS = (FOLD_T / 2) * RAW_WORDS;
+__device__ __forceinline__ void wg_tree_sum(Xyzz& acc, uint32_t* sh, uint32_t T, uint32_t t)
+{
+    constexpr uint32_t STRIDE = FOLD_T / 2;
+    for (uint32_t half = T >> 1; half >= 1; half >>= 1) {
+        if (t >= half && t < 2 * half) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                sh[(0 * NL + i) * STRIDE + t - half] = acc.x.d[i];
+                sh[(1 * NL + i) * STRIDE + t - half] = acc.y.d[i];
+                sh[(2 * NL + i) * STRIDE + t - half] = acc.zz.d[i];
+                sh[(3 * NL + i) * STRIDE + t - half] = acc.zzz.d[i];
+            }
+        }
+        __syncthreads();
+        if (t < half) {
+            Xyzz q, r;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                q.x.d[i] = sh[(0 * NL + i) * STRIDE + t];
+                q.y.d[i] = sh[(1 * NL + i) * STRIDE + t];
+                q.zz.d[i] = sh[(2 * NL + i) * STRIDE + t];
+                q.zzz.d[i] = sh[(3 * NL + i) * STRIDE + t];
+            }
+            add(r, acc, q);
+            acc = r;
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                               uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
                                                               uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logG)
 {
@@ -572,12 +615,12 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_merge_kernel(const uint32_t* 
         st32(buckets + (size_t)b * 32, o);
     }
 }
-// K4h: one workgroup per queued bucket: strided in-lane sums, then an LDS tree
-__global__ void __launch_bounds__(MSM_THREADS) msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+// K4h: one workgroup per queued bucket: strided in-lane sums, then the workgroup tree
+__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                                     uint32_t* __restrict__ buckets, const uint32_t* __restrict__ heavy, uint32_t ch)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
-    __shared__ uint32_t sh[MSM_THREADS * RAW_WORDS];
+    __shared__ uint32_t sh[FOLD_LDS_WORDS];
     const uint32_t count = heavy[0];
     for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
         const uint32_t b = heavy[1 + item];
@@ -591,140 +634,32 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_merge_heavy_kernel(const uint
             add(r, acc, q);
             acc = r;
         }
-        __syncthreads(); // previous item's readers are done with sh
-        store_raw(sh + threadIdx.x * RAW_WORDS, acc);
-        __syncthreads();
-        for (uint32_t half = MSM_THREADS / 2; half >= 1; half >>= 1) {
-            if (threadIdx.x < half) {
-                Xyzz p, q, r;
-                load_raw(p, sh + threadIdx.x * RAW_WORDS);
-                load_raw(q, sh + (threadIdx.x + half) * RAW_WORDS);
-                add(r, p, q);
-                store_raw(sh + threadIdx.x * RAW_WORDS, r);
-            }
-            __syncthreads();
-        }
+        __syncthreads(); // the previous item's wave 0 is done reading sh
+        wg_tree_sum(acc, sh, MSM_THREADS, threadIdx.x);
         if (threadIdx.x == 0) {
-            Xyzz r;
-            load_raw(r, sh);
             uint32_t o[32];
-            store_xyzz(o, r);
+            store_xyzz(o, acc);
             st32(buckets + (size_t)b * 32, o);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// K5: log-depth folds over arrays of XYZZ points (32 words each)
+// K5: sum_b (b + 1) B_b over a bucket set without a serial running sum
 // ---------------------------------------------------------------------------------------------------------------------
-struct FoldJob {
-    const uint32_t* in;
-    uint32_t* out;
-    uint32_t groups;      // independent segments
-    uint32_t half;        // out[g][j] = in[g][j] + in[g][j + half], j < half
-    uint32_t in_gstride;  // in points
-    uint32_t out_gstride;
-};
-struct FoldArgs {
-    FoldJob job[3];
-    uint32_t njobs;
-};
-__global__ void __launch_bounds__(MSM_THREADS) msm_fold_kernel(FoldArgs A)
-{
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
-    const FoldJob& J = A.job[blockIdx.y];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= J.groups * J.half) return;
-    const uint32_t g = t / J.half, j = t - g * J.half;
-    uint32_t w[32];
-    Xyzz p, q, r;
-    ld32(J.in + ((size_t)g * J.in_gstride + j) * 32, w);
-    load_xyzz(p, w);
-    ld32(J.in + ((size_t)g * J.in_gstride + j + J.half) * 32, w);
-    load_xyzz(q, w);
-    add(r, p, q);
-    store_xyzz(w, r);
-    st32(J.out + ((size_t)g * J.out_gstride + j) * 32, w);
-}
-
-// bit-sliced gather + first fold.  For every group g, bit k < bits (len = 2^bits), pair j < len/4:
-//   out[(g*bits + k)*(len/4) + j] = in[g*len + sel_k(2j)] + in[g*len + sel_k(2j+1)],  sel_k(m) = m-th index with bit k set.
-// len == 2 degenerates to a copy of in[g*2 + 1].
-struct SliceJob {
-    const uint32_t* in;
-    uint32_t* out;
-    uint32_t groups, bits, len;
-};
-struct SliceArgs {
-    SliceJob job[2];
-};
+// m-th index with bit k set
 __device__ __forceinline__ uint32_t insert_one_bit(uint32_t m, uint32_t k)
 {
     return ((m >> k) << (k + 1)) | (1u << k) | (m & ((1u << k) - 1));
 }
-__global__ void __launch_bounds__(MSM_THREADS) msm_slice_kernel(SliceArgs A)
-{
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
-    const SliceJob& J = A.job[blockIdx.y];
-    const uint32_t quarter = J.len >= 4 ? (J.len >> 2) : 1;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= J.groups * J.bits * quarter) return;
-    const uint32_t j = t % quarter, gk = t / quarter, k = gk % J.bits, g = gk / J.bits;
-    uint32_t w[32];
-    if (J.len == 2) {
-        ld32(J.in + ((size_t)g * 2 + 1) * 32, w);
-        st32(J.out + (size_t)t * 32, w);
-        return;
-    }
-    Xyzz p, q, r;
-    ld32(J.in + ((size_t)g * J.len + insert_one_bit(2 * j, k)) * 32, w);
-    load_xyzz(p, w);
-    ld32(J.in + ((size_t)g * J.len + insert_one_bit(2 * j + 1, k)) * 32, w);
-    load_xyzz(q, w);
-    add(r, p, q);
-    store_xyzz(w, r);
-    st32(J.out + (size_t)t * 32, w);
-}
 
-// ---- fused K5: two launches instead of ~20 ------------------------------------------------------------------------------
-// Workgroup tree sum over up to 256 XYZZ points held one per lane (raw lazy limbs through LDS, structure of arrays):
-// the dependent chain is log2(T) additions with no launch gaps in between.  Result in lane 0.
-constexpr int FOLD_T = 256;
-__device__ __forceinline__ void wg_tree_sum(Xyzz& acc, uint32_t* sh, uint32_t T, uint32_t t)
-{
-    for (uint32_t half = T >> 1; half >= 1; half >>= 1) {
-        if (t >= half && t < 2 * half) {
-#pragma unroll
-            for (int i = 0; i < NL; i++) {
-                sh[(0 * NL + i) * FOLD_T + t - half] = acc.x.d[i];
-                sh[(1 * NL + i) * FOLD_T + t - half] = acc.y.d[i];
-                sh[(2 * NL + i) * FOLD_T + t - half] = acc.zz.d[i];
-                sh[(3 * NL + i) * FOLD_T + t - half] = acc.zzz.d[i];
-            }
-        }
-        __syncthreads();
-        if (t < half) {
-            Xyzz q, r;
-#pragma unroll
-            for (int i = 0; i < NL; i++) {
-                q.x.d[i] = sh[(0 * NL + i) * FOLD_T + t];
-                q.y.d[i] = sh[(1 * NL + i) * FOLD_T + t];
-                q.zz.d[i] = sh[(2 * NL + i) * FOLD_T + t];
-                q.zzz.d[i] = sh[(3 * NL + i) * FOLD_T + t];
-            }
-            add(r, acc, q);
-            acc = r;
-        }
-        __syncthreads();
-    }
-}
 // Row sums R[hi] = sum_lo B[hi][lo] (blockIdx.x < H) and column sums C[lo] = sum_hi B[hi][lo] (blockIdx.x >= H) of the
 // H x L bucket matrix of group blockIdx.y; blockDim.x = max(H, L).
-__global__ void __launch_bounds__(FOLD_T) msm_rowcol_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
+__global__ void __launch_bounds__(FOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
                                                           uint32_t H, uint32_t L)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
-    __shared__ uint32_t sh[RAW_WORDS * FOLD_T];
+    __shared__ uint32_t sh[FOLD_LDS_WORDS];
     const uint32_t g = blockIdx.y, t = threadIdx.x, nb = H * L;
     const bool row = blockIdx.x < H;
     const uint32_t idx = row ? blockIdx.x : blockIdx.x - H, count = row ? L : H;
@@ -746,11 +681,11 @@ __global__ void __launch_bounds__(FOLD_T) msm_rowcol_kernel(const uint32_t* __re
 // Job 0: Z = sum R; job 1 + k: TR_k = sum of the R_hi whose bit k is set; job 1 + hbits + k: TC_k likewise over C.  Each job is
 // one workgroup; results go straight into the 64-slot export array in the reference's Montgomery form (slot 0 = Z,
 // 1 + k = TR_k, 32 + k = TC_k; the array is zeroed = infinity beforehand).
-__global__ void __launch_bounds__(FOLD_T) msm_final_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(FOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_final_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
                                                          uint32_t hbits, uint32_t lbits)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
-    __shared__ uint32_t sh[RAW_WORDS * FOLD_T];
+    __shared__ uint32_t sh[FOLD_LDS_WORDS];
     const uint32_t g = blockIdx.y, t = threadIdx.x, job = blockIdx.x;
     const uint32_t H = 1u << hbits, L = 1u << lbits;
     const uint32_t* src;
@@ -772,31 +707,6 @@ __global__ void __launch_bounds__(FOLD_T) msm_final_kernel(const uint32_t* __res
         store_xyzz_m256(o, acc);
         st32(out + ((size_t)g * 64 + slot) * 32, o);
     }
-}
-
-// final: per window gather Z, TR_k, TC_k into 64 slots and convert to the reference's Montgomery(2^256) words
-//   slot 0 = Z, 1 + k = TR_k (k < hbits), 32 + k = TC_k (k < lbits); unused slots are infinity
-__global__ void msm_collect_kernel(const uint32_t* __restrict__ z, const uint32_t* __restrict__ tr, const uint32_t* __restrict__ tc,
-                                   uint32_t* __restrict__ out, uint32_t nw, uint32_t hbits, uint32_t lbits)
-{
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nw * 64) return;
-    const uint32_t w = t >> 6, slot = t & 63;
-    const uint32_t* src = nullptr;
-    if (slot == 0) src = z + (size_t)w * 32;
-    else if (slot >= 1 && slot < 1 + hbits) src = tr + ((size_t)w * hbits + (slot - 1)) * 32;
-    else if (slot >= 32 && slot < 32 + lbits) src = tc + ((size_t)w * lbits + (slot - 32)) * 32;
-    uint32_t o[32];
-    Xyzz p;
-    if (src) {
-        ld32(src, o);
-        load_xyzz(p, o);
-    } else {
-        set_infinity(p);
-    }
-    store_xyzz_m256(o, p);
-    st32(out + (size_t)t * 32, o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -841,6 +751,15 @@ static uint32_t acc_wg_per_cu()
     }
     return (uint32_t)v;
 }
+static uint32_t acc_prio()
+{
+    static int v = -1;
+    if (v < 0) {
+        v = 0;
+        if (const char* e = getenv("BBGPU_ACC_PRIO")) v = std::min(2, std::max(0, atoi(e))); // tuning knob
+    }
+    return (uint32_t)v;
+}
 static uint32_t acc_capacity_lanes()
 {
     static uint32_t lanes = 0;
@@ -865,7 +784,7 @@ static uint32_t chunk_len(size_t n, uint32_t nw)
 static size_t arena_points(const MsmPlan& P, uint32_t nw)
 {
     const size_t H = (size_t)1 << P.hbits, L = (size_t)1 << P.lbits;
-    return (size_t)nw * (2 * P.nb + 2 * (P.hbits * H + P.lbits * L + 2 * H + 2 * L) + 64) + 4096;
+    return (size_t)nw * (H + L) + 64; // row sums + column sums per bucket set
 }
 static MsmPlan make_plan(size_t n, int c)
 {
@@ -1003,7 +922,6 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     uint32_t* partials = (uint32_t*)p; p += al(((size_t)nw * P.nb + chunks_cap) * RAW_WORDS * 4);
     uint32_t* buckets = (uint32_t*)p; p += al((size_t)nw * P.nb * 128);
     uint32_t* scratch = (uint32_t*)p; p += al(arena_points(P, nw) * 128);
-    uint32_t* scratch_end = (uint32_t*)p;
     uint32_t* texp = (uint32_t*)p;
 
     hipEvent_t* ev = S.ev;
@@ -1040,7 +958,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     while ((1u << logG) < avg_partials && logG < 6 && ((uint64_t)G * P.nb << (logG + 1)) <= (1u << 16)) logG++;
     const uint32_t merge_light = std::max(6u, 8u << logG);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
-    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch);
+    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch, acc_prio());
     if (tm) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
     msm_merge_kernel<<<(uint32_t)((((uint64_t)total_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
@@ -1052,9 +970,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     //   S_w = Z + sum_lo lo * C_lo + 2^l * sum_hi hi * R_hi,   R = row sums (over lo), C = column sums (over hi), Z = sum R
     //   sum_hi hi * R_hi = sum_k 2^k TR_k, TR_k = sum of the R_hi whose bit k is set (same for C).
     const uint32_t H = 1u << P.hbits, L = 1u << P.lbits;
-    static const bool legacy_k5 = getenv("BBGPU_K5_LEGACY") != nullptr; // A/B knob: the per-level fold launches
-    if (!legacy_k5) {
-        // fused: row + column sums in one launch (one workgroup tree per row / column), then Z and the bit-sliced sums in a second
+    {
+        // row + column sums in one launch (one workgroup tree per row / column), then Z and the bit-sliced sums in a second
         uint32_t* Rr = scratch;
         uint32_t* Cc = scratch + (size_t)G * H * 32;
         msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L);
@@ -1062,60 +979,6 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         HIPCHK(hipMemsetAsync(texp, 0, (size_t)G * 64 * 128, st)); // unused slots = infinity (zz = 0)
         msm_final_kernel<<<dim3(1 + P.hbits + P.lbits, G), std::max(H, L), 0, st>>>(Rr, Cc, texp, P.hbits, P.lbits);
         if (tm) HIPCHK(hipEventRecord(ev[6], st));
-    } else {
-    uint32_t* bump = scratch;
-    bool arena_overflow = false;
-    auto alloc_pts = [&](size_t count) {
-        uint32_t* r = bump;
-        bump += count * 32;
-        if (bump > scratch_end) { arena_overflow = true; bump = scratch; r = scratch; } // never write past the arena
-        return r;
-    };
-    struct Chain { const uint32_t* in; uint32_t groups, len, stop, gstride; };
-    auto run_chains = [&](Chain* ch, int nch) -> int {
-        for (;;) {
-            FoldArgs FA{};
-            uint32_t mt = 0;
-            for (int q = 0; q < nch; q++) {
-                Chain& C = ch[q];
-                if (C.len <= C.stop) continue;
-                FoldJob& J = FA.job[FA.njobs++];
-                J.in = C.in; J.groups = C.groups; J.half = C.len / 2; J.in_gstride = C.gstride; J.out_gstride = C.len / 2;
-                J.out = alloc_pts((size_t)C.groups * J.half);
-                mt = std::max(mt, J.groups * J.half);
-                C.in = J.out; C.len /= 2; C.gstride = C.len;
-            }
-            if (FA.njobs == 0) return BBGPU_OK;
-            msm_fold_kernel<<<dim3((mt + MSM_THREADS - 1) / MSM_THREADS, FA.njobs), MSM_THREADS, 0, st>>>(FA);
-        }
-    };
-    // rows: groups = (window, hi), contiguous length L -> 1.  cols: groups = window, length nb folded by halves of the hi
-    // range until L entries (the column sums) remain.
-    Chain rowcol[2] = { { buckets, G * H, L, 1, L }, { buckets, G, P.nb, L, P.nb } };
-    run_chains(rowcol, 2);
-    const uint32_t* R = rowcol[0].in;  // [nw][H]
-    const uint32_t* Cc = rowcol[1].in; // [nw][L]
-    if (tm) HIPCHK(hipEventRecord(ev[5], st));
-    uint32_t* trbuf = alloc_pts((size_t)G * P.hbits * std::max(1u, H / 4));
-    uint32_t* tcbuf = alloc_pts((size_t)G * std::max(1u, P.lbits) * std::max(1u, L / 4));
-    {
-        SliceArgs SA{};
-        uint32_t nj = 0, mt = 0;
-        if (P.hbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = R; J.out = trbuf; J.groups = G; J.bits = P.hbits; J.len = H; mt = std::max(mt, G * P.hbits * std::max(1u, H / 4)); }
-        if (P.lbits >= 1) { SliceJob& J = SA.job[nj++]; J.in = Cc; J.out = tcbuf; J.groups = G; J.bits = P.lbits; J.len = L; mt = std::max(mt, G * P.lbits * std::max(1u, L / 4)); }
-        if (nj) msm_slice_kernel<<<dim3((mt + MSM_THREADS - 1) / MSM_THREADS, nj), MSM_THREADS, 0, st>>>(SA);
-    }
-    Chain zt[3] = { { R, G, H, 1, H },
-                    { trbuf, G * P.hbits, std::max(1u, H / 4), 1, std::max(1u, H / 4) },
-                    { tcbuf, G * std::max(1u, P.lbits), std::max(1u, L / 4), 1, std::max(1u, L / 4) } };
-    run_chains(zt, 3);
-    if (arena_overflow) {
-        (void)hipStreamSynchronize(st);
-        set_error("internal: fold arena too small (n=%zu c=%u nw=%u)", n, P.c, nw);
-        return BBGPU_ERR_STATE;
-    }
-    msm_collect_kernel<<<(G * 64 + 127) / 128, 128, 0, st>>>(zt[0].in, zt[1].in, zt[2].in, texp, G, P.hbits, P.lbits);
-    if (tm) HIPCHK(hipEventRecord(ev[6], st));
     }
     HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(S.done, st));
