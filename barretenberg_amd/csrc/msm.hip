@@ -261,8 +261,9 @@ struct ScalarSets {
     const uint32_t* p[MSM_MAX_JOBS]; // one scalar vector per job of a batch (blockIdx.y)
 };
 __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, int16_t* __restrict__ digits_all,
-                                                               uint32_t n, WinLayout LO, uint32_t num_windows)
+                                                               uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we)
 {
+    // only windows [wb, we) are stored (a rank of a window-sharded MSM needs its share only); the carry chain still starts at window 0
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* __restrict__ scalars = sets.p[blockIdx.y];
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets
     for (int j = 0; j < 8; j++) k[j] = w[j];
     k[8] = 0;
     uint32_t carry = 0;
-    for (uint32_t win = 0; win < num_windows; win++) {
+    for (uint32_t win = 0; win < we; win++) {
         const uint32_t bit = LO.off[win], sz = LO.off[win + 1] - bit, j = bit >> 5, s = bit & 31;
         const uint32_t half = 1u << (sz - 1), mask = (1u << sz) - 1;
         uint32_t v = 0;
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets
         v = (v & mask) + carry;
         carry = (win + 1 < num_windows && v >= half) ? 1u : 0u;
         const int32_t d = (int32_t)v - (int32_t)(carry << sz);
-        digits[(size_t)win * n + i] = (int16_t)d;
+        if (win >= wb) digits[(size_t)win * n + i] = (int16_t)d;
     }
 }
 
@@ -936,7 +937,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     // K0
     ScalarSets sets{};
     for (int j = 0; j < jobs; j++) sets.p[j] = (const uint32_t*)d_scalars_v[j];
-    msm_digits_kernel<<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, digits, P.n, make_layout(c, table), P.W);
+    msm_digits_kernel<<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, digits, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
     sortA_hist_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);

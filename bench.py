@@ -180,7 +180,8 @@ def main():
 
     stage_log = []  # per-MSM stage times (HIP events on the stream the kernels ran on), filled while timing is on
 
-    def finish(ticket):
+    def collect(ticket):
+        """wait for this rank's MSM share; returns its normalised partial sum (96 bytes)"""
         if ticket is not None:
             part = G.msm_wait(ticket)
             tm = G.last_timing()
@@ -189,24 +190,50 @@ def main():
         else:
             part = np.zeros(12, dtype=np.uint64)
             part[7] = np.uint64(1 << 63)
-        if world == 1:
-            return part
-        mine = torch.from_numpy(part.view(np.int64)).to(xdev)
-        dist.all_gather(gather_buf, mine)  # the path's one exchange step: 96 bytes per rank over xGMI
-        allp = torch.stack(gather_buf).cpu().numpy().view(np.uint64)
-        return G.g1_sum(allp)
+        return part
+
+    def start_exchange(part):
+        """the path's one exchange step: 96 bytes per rank over xGMI (all-gather; RCCL has no G1 reduction operator), asynchronous
+        so that it overlaps the next step's kernels"""
+        mine = torch.from_numpy(part.view(np.int64).copy()).to(xdev)
+        bufs = [torch.empty(12, dtype=torch.int64, device=xdev) for _ in range(world)]
+        return dist.all_gather(bufs, mine, async_op=True), bufs, mine
+
+    def end_exchange(x):
+        work, bufs, _ = x
+        work.wait()
+        return G.g1_sum(torch.stack(bufs).cpu().numpy().view(np.uint64))  # identical fold on every rank
 
     def run_steps(k):
         """k complete MSMs; step i+1 is enqueued before step i is collected (two-slot pipeline of the library), so the
-        bucket-reduction tail + host finish of one step overlap the sort/accumulate of the next"""
-        res, inflight = None, []
+        bucket-reduction tail + host finish of one step overlap the sort/accumulate of the next; with N > 1 the exchange of
+        step i is in flight while step i+1 is collected"""
+        res, inflight, exchange = None, [], None
         for _ in range(k):
             inflight.append(issue())
             if len(inflight) == 2:
-                res = finish(inflight.pop(0))
+                part = collect(inflight.pop(0))
+                if world == 1:
+                    res = part
+                else:
+                    if exchange is not None:
+                        res = end_exchange(exchange)
+                    exchange = start_exchange(part)
         while inflight:
-            res = finish(inflight.pop(0))
+            part = collect(inflight.pop(0))
+            if world == 1:
+                res = part
+            else:
+                if exchange is not None:
+                    res = end_exchange(exchange)
+                exchange = start_exchange(part)
+        if exchange is not None:
+            res = end_exchange(exchange)
         return res
+
+    def finish(ticket):
+        part = collect(ticket)
+        return part if world == 1 else end_exchange(start_exchange(part))
 
     res = run_steps(args.warmup)
     # live per-kernel timing INSIDE the timed region: the library brackets every stage with HIP events on the stream the
@@ -231,6 +258,12 @@ def main():
         finish(issue())
     barrier()
     msm_latency_ms = (time.perf_counter() - t0) / 5 * 1e3
+
+    # window-sharded result == the same MSM done by one rank alone (outside the timed region)
+    sharded_ok = None
+    if world > 1:
+        full = G.msm_device(srs, d_scalars.data_ptr(), n, 0, 0, W)
+        sharded_ok = bool(np.array_equal(full, res))
 
     # ---- the same stages with nothing else on the GPU (one MSM at a time), for comparison ---------------------------
     G.set_timing(True)
@@ -318,6 +351,8 @@ def main():
                                  "frac": ntt_bytes / (ntt["fft"]["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                  "kernel": "ntt_pass_kernel x2"}},
         }
+        if sharded_ok is not None:
+            line["sharded_result_equals_single_gpu"] = sharded_ok
         if plonk is not None:
             line["plonk"] = plonk
         if cpu_leg:
