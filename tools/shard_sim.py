@@ -15,20 +15,33 @@ srs = G.srs_generate(x, n)
 sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64); sc[:, 3] &= np.uint64(0x1FFFFFFFFFFFFFFF)
 d = torch.from_numpy(sc.view(np.int64)).cuda()
 W = G.srs_num_windows(srs, n)
+base = None
 for N in (1, 2, 4, 8):
     we = W // N
-    def run(k):
-        infl = []
-        for _ in range(k):
-            infl.append(G.msm_device_async(srs, d.data_ptr(), n, 0, 0, we))
-            if len(infl) == 2:
+    for depth in (1, 2, 3, 4):
+        def run(k):
+            infl = []
+            for _ in range(k):
+                infl.append(G.msm_device_async(srs, d.data_ptr(), n, 0, 0, we))
+                if len(infl) == depth:
+                    G.msm_wait(infl.pop(0))
+            while infl:
                 G.msm_wait(infl.pop(0))
-        while infl:
-            G.msm_wait(infl.pop(0))
-    run(3)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); run(20); dt = (time.perf_counter() - t0) / 20
-    t0 = time.perf_counter()
-    for _ in range(5): G.msm_wait(G.msm_device_async(srs, d.data_ptr(), n, 0, 0, we))
-    lat = (time.perf_counter() - t0) / 5
-    print("N=%d: %2d windows per rank: %.3f ms/step pipelined (speed-up %.2fx of N), %.3f ms latency" % (N, we, dt * 1e3, 0, lat * 1e3), flush=True)
+        run(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); run(24); dt = (time.perf_counter() - t0) / 24
+        if base is None and depth == 2:
+            base = dt
+        print("N=%d (%2d windows per rank), %d in flight: %.3f ms/step%s" % (N, we, depth, dt * 1e3, "  = %.2fx of N=1" % (base / dt) if base else ""), flush=True)
+
+# host-side cost of one step at the smallest share: time inside the two calls
+we = W // 8
+ti = tw = 0.0
+infl = []
+for _ in range(40):
+    t0 = time.perf_counter(); infl.append(G.msm_device_async(srs, d.data_ptr(), n, 0, 0, we)); ti += time.perf_counter() - t0
+    if len(infl) == 2:
+        t0 = time.perf_counter(); G.msm_wait(infl.pop(0)); tw += time.perf_counter() - t0
+while infl:
+    G.msm_wait(infl.pop(0))
+print("N=8 share, 2 in flight: %.3f ms inside msm_device_async (launches), %.3f ms inside msm_wait (event wait + host finish) per step" % (ti / 40 * 1e3, tw / 40 * 1e3))
