@@ -96,6 +96,8 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
     return BBGPU_OK;
 }
 
+constexpr size_t AUTO_REGISTER_MIN_POINTS = 1024; // host-pointer MSMs against unknown tables below this size do not cache the table
+
 // registers resident points; builds the pre-shifted window tables when enabled and the 24-bit row index allows it
 int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs)
 {
@@ -161,28 +163,43 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         set_error("null scalars/points");
         return BBGPU_ERR_ARG;
     }
-    size_t off = 0;
-    int idx = find_srs(points, n, &off);
-    if (idx < 0) {
-        uint32_t* d = nullptr;
-        int rc = srs_upload(points, n, &d, g_ctx.stream);
-        if (rc) return rc;
-        idx = add_srs(points, n, d);
-        if (idx < 0) return idx;
-        off = 0;
-    }
-    int rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
-    if (rc) return rc;
-    CHK(hipMemcpyAsync(g_ctx.d_stage, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
-    host::Xyzz res;
-    const int W = entry_windows(g_ctx.srs[idx], n);
     if (g_ctx.slot[0].pending) {
         set_error("an asynchronous MSM is still in flight on slot 0: wait for it first");
         return BBGPU_ERR_STATE;
     }
-    rc = issue_on_entry(g_ctx.slot[0], g_ctx.srs[idx], off, g_ctx.d_stage, n, 0, W, g_ctx.stream);
-    if (rc) return rc;
-    rc = msm_finish(g_ctx.slot[0], &res, &g_ctx.last);
+    size_t off = 0;
+    int idx = find_srs(points, n, &off);
+    // A table that was never registered and is too small to be an SRS (the verifier's ~20 freshly built points,
+    // verifier.cpp:359-363) is used once and forgotten: caching it by address would both leak device memory per call and
+    // serve stale points when the caller's vector is freed and its address reused.  Larger unknown tables are taken to be a
+    // long-lived SRS and registered on first sight.
+    SrsEntry transient{};
+    const bool is_transient = idx < 0 && n < AUTO_REGISTER_MIN_POINTS;
+    if (idx < 0) {
+        uint32_t* d = nullptr;
+        int rc = srs_upload(points, n, &d, g_ctx.stream);
+        if (rc) return rc;
+        if (is_transient) {
+            transient.host_ptr = points;
+            transient.n = n;
+            transient.d_srs = d;
+            transient.live = true;
+        } else {
+            idx = add_srs(points, n, d);
+            if (idx < 0) return idx;
+        }
+        off = 0;
+    }
+    const SrsEntry& e = is_transient ? transient : g_ctx.srs[idx];
+    int rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
+    if (rc == BBGPU_OK && hipMemcpyAsync(g_ctx.d_stage, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess) {
+        set_error("scalar upload failed");
+        rc = BBGPU_ERR_HIP;
+    }
+    host::Xyzz res;
+    if (rc == BBGPU_OK) rc = issue_on_entry(g_ctx.slot[0], e, off, g_ctx.d_stage, n, 0, entry_windows(e, n), g_ctx.stream);
+    if (rc == BBGPU_OK) rc = msm_finish(g_ctx.slot[0], &res, &g_ctx.last);
+    if (is_transient) (void)hipFree(transient.d_srs); // msm_finish has waited for the kernels
     if (rc) return rc;
     host::g1_to_normalised(res, out);
     return BBGPU_OK;

@@ -290,6 +290,23 @@ def test_msm_additivity_large(gpu, oracle):
         gpu.srs_release(h)
 
 
+def test_msm_small_unregistered_tables_are_not_cached(gpu, oracle, msm_small):
+    """the verifier builds a fresh ~20-point table per proof (verifier.cpp:359-363): the same host buffer refilled with OTHER points
+    must give the new result (no stale resident copy keyed by the address), call after call"""
+    g, srs, table, scalars = msm_small
+    n = 24
+    buf = aligned_copy(table[:2 * n])
+    sc = aligned_copy(scalars[:n])
+    first = gpu.pippenger(sc, buf, n)
+    assert np.array_equal(first[:8], oracle.msm_affine(sc, aligned_copy(table[:2 * n]), n)[:8])
+    buf[...] = table[2 * 100:2 * 100 + 2 * n]  # same address, different points
+    second = gpu.pippenger(sc, buf, n)
+    assert np.array_equal(second[:8], oracle.msm_affine(sc, aligned_copy(table[200:200 + 2 * n]), n)[:8])
+    assert not np.array_equal(first, second)
+    for _ in range(50):  # and no per-call registration piling up
+        assert np.array_equal(gpu.pippenger(sc, buf, n), second)
+
+
 def test_msm_device_batch(gpu, oracle, msm_small):
     """whole-batch entry: up to four scalar vectors over the same points in one pass = the single MSMs, including
     an all-zero vector, a skewed one, and sub-ranges of the registered table"""
