@@ -44,7 +44,7 @@ C_ABI_SYMBOLS = [
     "bbgpu_permutation_lagrange_base_device",
     "bbgpu_fr_evaluate", "bbgpu_kate_opening", "bbgpu_lagrange_l1_fft", "bbgpu_divide_by_pseudo_vanishing", "bbgpu_lagrange_evaluations",
     "bbgpu_generate_point_table",
-    "bbgpu_plonk_prover_create", "bbgpu_plonk_prover_set_witness", "bbgpu_plonk_construct_proof", "bbgpu_plonk_last_challenges",
+    "bbgpu_plonk_prover_create", "bbgpu_plonk_prover_set_witness", "bbgpu_plonk_construct_proof", "bbgpu_plonk_preprocess", "bbgpu_plonk_last_challenges",
     "bbgpu_plonk_last_timing", "bbgpu_plonk_prover_destroy", "bbgpu_plonk_challenges_from_proof",
 ]
 

@@ -494,6 +494,24 @@ class PlonkProver {
         memcpy(proof.PI_Z_OMEGA, out[1], 64);
         return BBGPU_OK;
     }
+    // waffle::preprocess(prover) (preprocess.hpp:16-55) + ProverArithmeticWidget::compute_preprocessed_commitments
+    // (arithmetic_widget.cpp:128-157): the verification key -- commitments to sigma_1..3 and to q_m, q_l, q_r, q_o, q_c
+    int preprocess(uint64_t (*out)[8])
+    {
+        RC(prepare_circuit());
+        // sigma polynomials in coefficient form, unscaled (the proof rounds scale them by beta)
+        RC(copy(tmp[0], sigma_lagrange[0], n));
+        RC(copy(tmp[1], sigma_lagrange[1], n));
+        RC(copy(tmp[2], sigma_lagrange[2], n));
+        for (int k = 0; k < 3; k++) RC(ntt(tmp[k], n, BBGPU_IFFT));
+        const uint64_t* s3[3] = { tmp[0], tmp[1], tmp[2] };
+        RC(commit(s3, 3, out));
+        const uint64_t* q3[3] = { q_coeff[0], q_coeff[1], q_coeff[2] };
+        RC(commit(q3, 3, out + 3));
+        const uint64_t* q2[2] = { q_coeff[3], q_coeff[4] };
+        RC(commit(q2, 2, out + 6));
+        return BBGPU_OK;
+    }
     // prover.cpp:661-670
     int construct_proof()
     {
@@ -585,6 +603,14 @@ int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF
     if (rc) return rc;
     memcpy(proof_out, &p->proof, sizeof(Proof));
     return BBGPU_OK;
+}
+
+int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[64])
+{
+    std::lock_guard<std::mutex> lk(g_pmu);
+    PlonkProver* p = get(prover);
+    if (!p || !vk_out) return BBGPU_ERR_ARG;
+    return p->preprocess(reinterpret_cast<uint64_t(*)[8]>(vk_out));
 }
 
 int bbgpu_plonk_last_challenges(int prover, uint64_t out[20])

@@ -16,6 +16,7 @@ NO_WITNESS = 0xFFFFFFFF
 LEFT, RIGHT, OUTPUT = 0, 1 << 30, 1 << 31  # ComposerBase::WireType, composer_base.hpp:73-79
 
 PROOF_POINTS = ["W_L", "W_R", "W_O", "Z_1", "T_LO", "T_MID", "T_HI", "PI_Z", "PI_Z_OMEGA"]
+VK_POINTS = ["SIGMA_1", "SIGMA_2", "SIGMA_3", "Q_M", "Q_L", "Q_R", "Q_O", "Q_C"]
 PROOF_EVALS = ["w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval"]
 
 
@@ -205,6 +206,13 @@ class Prover:
         out = np.zeros(100, dtype=np.uint64)
         self.gpu._chk(self.gpu.lib.bbgpu_plonk_construct_proof(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out
+
+    def preprocess(self):
+        """waffle::preprocess(prover): -> dict of the eight verification-key commitments, each (8,) uint64 affine"""
+        out = np.zeros(64, dtype=np.uint64)
+        self.gpu.lib.bbgpu_plonk_preprocess.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+        self.gpu._chk(self.gpu.lib.bbgpu_plonk_preprocess(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return {k: out[8 * i:8 * i + 8] for i, k in enumerate(VK_POINTS)}
 
     def challenges(self):
         out = np.zeros(20, dtype=np.uint64)

@@ -180,6 +180,9 @@ typedef struct {
 int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* circuit, int srs_handle); /* returns a prover handle >= 0 */
 int bbgpu_plonk_prover_set_witness(int prover, const uint64_t* w_l, const uint64_t* w_r, const uint64_t* w_o);
 int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF_WORDS]); /* Prover::construct_proof, prover.cpp:661-670 */
+/* waffle::preprocess(prover) (preprocess.hpp:16-55, arithmetic_widget.cpp:128-157): the verification key of the circuit --
+ * SIGMA_1, SIGMA_2, SIGMA_3, then the commitments to q_m, q_l, q_r, q_o, q_c (affine x, y: 8 limbs each) */
+int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[64]);
 int bbgpu_plonk_last_challenges(int prover, uint64_t out[20]); /* beta, gamma, alpha, z, nu (waffle_types.hpp:9-16) */
 int bbgpu_plonk_last_timing(int prover, double ms_out[4]);     /* construct_proof wall ms: total, in commitments, rest, first-use preparation */
 int bbgpu_plonk_prover_destroy(int prover);

@@ -12,6 +12,8 @@
 //   plonk_xxx prove <num_gates>                build the add/mul-chain circuit of test/benchmarks/bench_plonk.cpp:25-37 with
 //                                              fixed witnesses, prove, verify, print
 //   plonk_xxx trace <num_gates>                prove + also print the Fiat-Shamir challenges (debugging aid for restatements)
+//   plonk_xxx vk <num_gates>                   print the verification key waffle::preprocess() derives from the prover state: SIGMA_1..3 and the
+//                                              arithmetic widget's five selector commitments (preprocess.hpp:16-55, arithmetic_widget.cpp:128-157)
 //   plonk_xxx dump <num_gates> <path>          write the waffle::Prover INPUT state the composer produced (witness values,
 //                                              sigma mappings, selector values) as a flat binary file: the input of the native
 //                                              resident prover (bbgpu_plonk_*), so that it proves the very same circuit
@@ -168,6 +170,29 @@ int dump(size_t num_gates, const char* path)
     return 0;
 }
 
+int vk(size_t num_gates)
+{
+    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
+    build_circuit(composer, num_gates);
+    waffle::Prover prover = composer.preprocess();
+    waffle::Verifier verifier = waffle::preprocess(prover);
+    printf("n %zu\n", prover.n);
+    const g1::affine_element* pts[3] = { &verifier.SIGMA_1, &verifier.SIGMA_2, &verifier.SIGMA_3 };
+    const char* pn[3] = { "SIGMA_1", "SIGMA_2", "SIGMA_3" };
+    char nm[32];
+    for (int i = 0; i < 3; i++) {
+        snprintf(nm, sizeof nm, "%s.x", pn[i]); hex4(nm, pts[i]->x.data);
+        snprintf(nm, sizeof nm, "%s.y", pn[i]); hex4(nm, pts[i]->y.data);
+    }
+    const char* qn[5] = { "Q_M", "Q_L", "Q_R", "Q_O", "Q_C" };
+    const auto& inst = verifier.verifier_widgets[0]->instance;
+    for (int i = 0; i < 5; i++) {
+        snprintf(nm, sizeof nm, "%s.x", qn[i]); hex4(nm, inst[i].x.data);
+        snprintf(nm, sizeof nm, "%s.y", qn[i]); hex4(nm, inst[i].y.data);
+    }
+    return 0;
+}
+
 bool rd4(const char* want, uint64_t* d)
 {
     char name[64], hex[80];
@@ -211,8 +236,9 @@ int main(int argc, char** argv)
     if (argc >= 4 && !strcmp(argv[1], "transcript")) return write_transcript(argv[2], (size_t)atol(argv[3]));
     if (argc >= 3 && !strcmp(argv[1], "prove")) return prove((size_t)atol(argv[2]), false);
     if (argc >= 3 && !strcmp(argv[1], "trace")) return prove((size_t)atol(argv[2]), true);
+    if (argc >= 3 && !strcmp(argv[1], "vk")) return vk((size_t)atol(argv[2]));
     if (argc >= 4 && !strcmp(argv[1], "dump")) return dump((size_t)atol(argv[2]), argv[3]);
     if (argc >= 3 && !strcmp(argv[1], "verify")) return verify((size_t)atol(argv[2]));
-    fprintf(stderr, "usage: %s transcript <path> <num_points> | prove|trace|verify <num_gates> | dump <num_gates> <path>\n", argv[0]);
+    fprintf(stderr, "usage: %s transcript <path> <num_points> | prove|trace|verify|vk <num_gates> | dump <num_gates> <path>\n", argv[0]);
     return 64;
 }

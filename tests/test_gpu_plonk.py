@@ -192,6 +192,21 @@ def test_resident_prover_proof_is_byte_identical(gpu, srs_for, golden, gates):
         for name in ("gamma", "beta", "alpha", "z", "nu"):
             assert hx(ch[name])[0] == tr["challenges"][str(gates)][name], name
         assert got == want[:26]
+        # the verification key waffle::preprocess() derives (SIGMA_1..3, Q_M..Q_C commitments) equals the reference's
+        if str(gates) in tr["verification_keys"]:
+            from barretenberg_amd.plonk import VK_POINTS, hex4
+            from oracle.pyoracle import Oracle
+            vk = prover.preprocess()
+            ref = {ln.split()[0]: ln.split()[1] for ln in tr["verification_keys"][str(gates)][1:]}
+            for k in VK_POINTS:
+                if int(vk[k][7]) >> 63:
+                    # commitment to the zero polynomial (q_c of this circuit): the point at infinity.  The reference pushes its infinity
+                    # through jacobian_to_affine and stores an off-curve pair, which its verifier then skips
+                    # (`if (g1::on_curve(instance[i]))`, arithmetic_widget.cpp:190-230) -- nothing to compare but that
+                    rp = np.array([int(ref[k + c][16 * (3 - j):16 * (4 - j)], 16) for c in (".x", ".y") for j in range(4)], dtype=np.uint64)
+                    assert not Oracle().g1_on_curve(rp), k
+                    continue
+                assert hex4(vk[k][0:4]) == ref[k + ".x"] and hex4(vk[k][4:8]) == ref[k + ".y"], k
         # proving again (cached circuit state, same witness) and after re-uploading the witness gives the same bytes
         assert np.array_equal(prover.construct_proof(), proof)
         prover.set_witness(state["w_l"], state["w_r"], state["w_o"])

@@ -45,7 +45,7 @@ def main():
     out = {"source": "oracle/_ref/plonk_cpu {trace,dump} <gates> (the reference's own composer and prover; see tools/gen_plonk_golden.py)",
            "witness_a0": "0777777788888888555555556666666633333333444444441111111122222222",
            "witness_b0": "0abcdefabcdefabc1234123412341234ddddeeeeffff00009999aaaabbbbcccc",
-           "challenges": {}, "input_digests": {}}
+           "challenges": {}, "input_digests": {}, "verification_keys": {}}
     big = os.environ.get("BBGPU_BIG_SRS_DIR")
     proofs_path = os.path.join(ROOT, "tests", "golden", "plonk_proofs.json")
     proofs = json.load(open(proofs_path))
@@ -56,6 +56,9 @@ def main():
             proofs["proofs"][str(gates)] = [ln for ln in lines if ln.split()[0] not in ("beta", "gamma", "alpha", "z", "nu")]
         ch = {ln.split()[0]: ln.split()[1] for ln in lines if ln.split()[0] in ("beta", "gamma", "alpha", "z", "nu")}
         out["challenges"][str(gates)] = ch
+        if gates <= 65536:  # waffle::preprocess(prover): SIGMA_1..3 and the widget's selector commitments (`plonk_cpu vk`)
+            out["verification_keys"][str(gates)] = subprocess.run([EXE, "vk", str(gates)], cwd=ROOT, capture_output=True, text=True,
+                                                                  check=True).stdout.strip().split("\n")
         path = "/tmp/plonk_dump_%d.bin" % gates
         subprocess.run([EXE, "dump", str(gates), path], cwd=big if gates > 65536 else ROOT, check=True, stdout=subprocess.DEVNULL)
         st = load_dump(path)
@@ -67,7 +70,7 @@ def main():
         os.remove(path)
     if not big:  # keep the large-circuit entries of an earlier run
         old = json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_trace.json")))
-        for key in ("challenges", "input_digests"):
+        for key in ("challenges", "input_digests", "verification_keys"):
             for g, v in old.get(key, {}).items():
                 out[key].setdefault(g, v)
     else:
