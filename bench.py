@@ -25,6 +25,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from barretenberg_amd import BbGpu  # noqa: E402
+from barretenberg_amd.sharding import PartialSumExchange, pipelined_steps  # noqa: E402
 
 LOG2N = 20
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
@@ -173,7 +174,6 @@ def main():
     W = G.srs_num_windows(srs, n)
     wb, we = W * rank // world, W * (rank + 1) // world
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the 96-byte partial sums are exchanged
-    gather_buf = [torch.empty(12, dtype=torch.int64, device=xdev) for _ in range(world)] if world > 1 else None
 
     def issue():
         return G.msm_device_async(srs, d_scalars.data_ptr(), n, 0, wb, we) if we > wb else None
@@ -192,48 +192,18 @@ def main():
             part[7] = np.uint64(1 << 63)
         return part
 
-    def start_exchange(part):
-        """the path's one exchange step: 96 bytes per rank over xGMI (all-gather; RCCL has no G1 reduction operator), asynchronous
-        so that it overlaps the next step's kernels"""
-        mine = torch.from_numpy(part.view(np.int64).copy()).to(xdev)
-        bufs = [torch.empty(12, dtype=torch.int64, device=xdev) for _ in range(world)]
-        return dist.all_gather(bufs, mine, async_op=True), bufs, mine
-
-    def end_exchange(x):
-        work, bufs, _ = x
-        work.wait()
-        return G.g1_sum(torch.stack(bufs).cpu().numpy().view(np.uint64))  # identical fold on every rank
+    exchange = PartialSumExchange(G, world, xdev) if world > 1 else None
 
     def run_steps(k):
         """k complete MSMs; step i+1 is enqueued before step i is collected (two-slot pipeline of the library), so the
         bucket-reduction tail + host finish of one step overlap the sort/accumulate of the next; with N > 1 the exchange of
-        step i is in flight while step i+1 is collected"""
-        res, inflight, exchange = None, [], None
-        for _ in range(k):
-            inflight.append(issue())
-            if len(inflight) == 2:
-                part = collect(inflight.pop(0))
-                if world == 1:
-                    res = part
-                else:
-                    if exchange is not None:
-                        res = end_exchange(exchange)
-                    exchange = start_exchange(part)
-        while inflight:
-            part = collect(inflight.pop(0))
-            if world == 1:
-                res = part
-            else:
-                if exchange is not None:
-                    res = end_exchange(exchange)
-                exchange = start_exchange(part)
-        if exchange is not None:
-            res = end_exchange(exchange)
-        return res
+        step i is in flight while step i+1 is collected (barretenberg_amd/sharding.py)"""
+        out = pipelined_steps(k, issue, collect, exchange)
+        return out[-1] if out else None
 
     def finish(ticket):
         part = collect(ticket)
-        return part if world == 1 else end_exchange(start_exchange(part))
+        return part if world == 1 else exchange.finish(exchange.start(part))
 
     res = run_steps(args.warmup)
     # live per-kernel timing INSIDE the timed region: the library brackets every stage with HIP events on the stream the
