@@ -86,6 +86,11 @@ class PlonkProver {
     uint64_t* q_coeff[5] = {};        // selector polynomials, coefficient form
     uint64_t* q_fft2n[5] = {};        // their coset evaluations on the 2n domain (unscaled)
     uint64_t* l_1 = nullptr;          // L_1 on the 2n coset
+    // optional bool widget (bool_widget.hpp): q_bl, q_br, q_bo
+    bool has_bool = false;
+    uint64_t* qb_lagrange[3] = {};
+    uint64_t* qb_coeff[3] = {};
+    uint64_t* qb_fft2n[3] = {};
     // per proof
     uint64_t* w[3] = {};        // wire polynomials, coefficient form          (Prover::w_l, w_r, w_o after :130-132)
     uint64_t* sigma[3] = {};    // beta * sigma_i, coefficient form             (after :245-247)
@@ -161,6 +166,19 @@ class PlonkProver {
             q_coeff[k] = q_coeff[0] + (size_t)k * n * 4;
             q_fft2n[k] = q_fft2n[0] + (size_t)k * 2 * n * 4;
             HIPCHK(hipMemcpy(q_lagrange[k], hq[k], fb, hipMemcpyHostToDevice));
+        }
+        const uint64_t* hb[3] = { c->q_bl, c->q_br, c->q_bo };
+        has_bool = hb[0] != nullptr;
+        if (has_bool) {
+            RC(dalloc(&qb_lagrange[0], 3 * fb));
+            RC(dalloc(&qb_coeff[0], 3 * fb));
+            RC(dalloc(&qb_fft2n[0], 6 * fb));
+            for (int k = 0; k < 3; k++) {
+                qb_lagrange[k] = qb_lagrange[0] + (size_t)k * n * 4;
+                qb_coeff[k] = qb_coeff[0] + (size_t)k * n * 4;
+                qb_fft2n[k] = qb_fft2n[0] + (size_t)k * 2 * n * 4;
+                HIPCHK(hipMemcpy(qb_lagrange[k], hb[k], fb, hipMemcpyHostToDevice));
+            }
         }
         RC(dalloc(&roots, fb));
         RC(dalloc(&l_1, 2 * fb));
@@ -265,6 +283,12 @@ class PlonkProver {
         RC(ntt_batch(q_coeff[0], n, 5, BBGPU_IFFT));
         for (int k = 0; k < 5; k++) RC(poly::copy_pad(q_fft2n[k], q_coeff[k], n, 2 * n, st));
         RC(ntt_batch(q_fft2n[0], 2 * n, 5, BBGPU_COSET_FFT));
+        if (has_bool) { // bool_widget.cpp:64-74 without the alpha scalings (applied in quotient_bool)
+            RC(copy(qb_coeff[0], qb_lagrange[0], 3 * n));
+            RC(ntt_batch(qb_coeff[0], n, 3, BBGPU_IFFT));
+            for (int k = 0; k < 3; k++) RC(poly::copy_pad(qb_fft2n[k], qb_coeff[k], n, 2 * n, st));
+            RC(ntt_batch(qb_fft2n[0], 2 * n, 3, BBGPU_COSET_FFT));
+        }
         RC(poly::lagrange_l1_fft(l_1, quotient_mid, log2n, log2n + 1, scratch, st)); // prover.cpp:350-351 (quotient_mid as workspace)
         HIPCHK(hipStreamSynchronize(st));
         circuit_ready = true;
@@ -358,6 +382,15 @@ class PlonkProver {
         M.q = (uint32_t*)quotient_mid;
         M.n2 = (uint32_t)n2;
         RC(poly::quotient_mid(M, challenges.alpha, alpha_base, st));
+        if (has_bool) { // the widget chain: the arithmetic widget hands on alpha_base * alpha (arithmetic_widget.cpp:103), the bool widget uses it and the next two powers
+            const Fr a5 = host::fr_mul(alpha_base, challenges.alpha), a6 = host::fr_mul(a5, challenges.alpha), a7 = host::fr_mul(a6, challenges.alpha);
+            poly::QuotBoolArgs Bq{};
+            Bq.wl_f = M.wl_f; Bq.wr_f = M.wr_f; Bq.wo_f = M.wo_f;
+            Bq.qbl_f = (const uint32_t*)qb_fft2n[0]; Bq.qbr_f = (const uint32_t*)qb_fft2n[1]; Bq.qbo_f = (const uint32_t*)qb_fft2n[2];
+            Bq.q = (uint32_t*)quotient_mid;
+            Bq.n2 = (uint32_t)n2;
+            RC(poly::quotient_bool(Bq, a5, a6, a7, st));
+        }
         return BBGPU_OK;
     }
     // prover.cpp:405-465 (after the wire / Z parts above)
@@ -437,11 +470,16 @@ class PlonkProver {
         const Fr alpha4 = host::fr_sqr(host::fr_sqr(alpha));
         const Fr w_lr = host::fr_mul(proof.w_l_eval, proof.w_r_eval);
         poly::LinCombArgs A{};
-        const uint64_t* ps[7] = { z, sigma[2], q_coeff[0], q_coeff[1], q_coeff[2], q_coeff[3], q_coeff[4] };
-        const Fr cs[7] = { lt_z1, host::fr_mul(lt_sigma3, beta_inv), host::fr_mul(w_lr, alpha4), host::fr_mul(proof.w_l_eval, alpha4),
-                           host::fr_mul(proof.w_r_eval, alpha4), host::fr_mul(proof.w_o_eval, alpha4), alpha4 };
-        for (int j = 0; j < 7; j++) A.p[j] = (const uint32_t*)ps[j];
-        A.count = 7;
+        const uint64_t* ps[10] = { z, sigma[2], q_coeff[0], q_coeff[1], q_coeff[2], q_coeff[3], q_coeff[4], qb_coeff[0], qb_coeff[1], qb_coeff[2] };
+        // bool_widget.cpp:106-124: (w^2 - w) alpha^5, alpha^6, alpha^7 on q_bl, q_br, q_bo
+        const Fr alpha5 = host::fr_mul(alpha4, alpha), alpha6 = host::fr_mul(alpha5, alpha), alpha7 = host::fr_mul(alpha6, alpha);
+        auto boolmul = [](const Fr& e, const Fr& a) { return host::fr_mul(host::fr_sub(host::fr_sqr(e), e), a); };
+        const Fr cs[10] = { lt_z1, host::fr_mul(lt_sigma3, beta_inv), host::fr_mul(w_lr, alpha4), host::fr_mul(proof.w_l_eval, alpha4),
+                            host::fr_mul(proof.w_r_eval, alpha4), host::fr_mul(proof.w_o_eval, alpha4), alpha4,
+                            boolmul(proof.w_l_eval, alpha5), boolmul(proof.w_r_eval, alpha6), boolmul(proof.w_o_eval, alpha7) };
+        const int terms = has_bool ? 10 : 7;
+        for (int j = 0; j < terms; j++) A.p[j] = (const uint32_t*)ps[j];
+        A.count = terms;
         A.out = (uint32_t*)r;
         A.n = (uint32_t)n;
         RC(poly::lincomb(A, cs, st));
@@ -510,6 +548,10 @@ class PlonkProver {
         RC(commit(q3, 3, out + 3));
         const uint64_t* q2[2] = { q_coeff[3], q_coeff[4] };
         RC(commit(q2, 2, out + 6));
+        if (has_bool) { // bool_widget.cpp:118-152
+            const uint64_t* qb[3] = { qb_coeff[0], qb_coeff[1], qb_coeff[2] };
+            RC(commit(qb, 3, out + 8));
+        }
         return BBGPU_OK;
     }
     // prover.cpp:661-670
@@ -566,6 +608,10 @@ int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* c, int srs_handle)
         set_error("null circuit field");
         return BBGPU_ERR_ARG;
     }
+    if ((c->q_bl != nullptr) != (c->q_br != nullptr) || (c->q_bl != nullptr) != (c->q_bo != nullptr)) {
+        set_error("bool widget selectors: give all of q_bl, q_br, q_bo or none");
+        return BBGPU_ERR_ARG;
+    }
     if (c->n < 4 || (c->n & (c->n - 1)) || c->n > ((size_t)1 << 20)) {
         set_error("circuit size %zu: must be a power of two, 4 <= n <= 2^20 (the 4n transforms go up to 2^22)", c->n);
         return BBGPU_ERR_SIZE;
@@ -605,7 +651,7 @@ int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF
     return BBGPU_OK;
 }
 
-int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[64])
+int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[BBGPU_PLONK_VK_WORDS])
 {
     std::lock_guard<std::mutex> lk(g_pmu);
     PlonkProver* p = get(prover);

@@ -45,6 +45,13 @@ struct QuotMidArgs {
     uint32_t n2;
     Limbs9 alpha_m256, alpha_fix_m261, alpha2_fix_m261, abase_m261, abase_fix2_m261, abase_fix3_m261;
 };
+struct QuotBoolArgs {
+    const uint32_t *wl_f, *wr_f, *wo_f;    // 4n coset evaluations (read at index 2i)
+    const uint32_t *qbl_f, *qbr_f, *qbo_f; // 2n coset evaluations of the bool selectors, unscaled
+    uint32_t* q;                           // quotient_mid, accumulated into
+    uint32_t n2;
+    Limbs9 cl_fix_m261, cr_fix_m261, co_fix_m261; // alpha powers times 2^5
+};
 struct LinCombArgs {
     const uint32_t* p[10];
     Limbs9 c[10];
@@ -103,6 +110,7 @@ int z_terms(ZTermsArgs A, const host::Fr& root, const host::Fr& beta, const host
 int sigma_prepare(uint64_t* d_dst, const uint64_t* d_sigma, const uint64_t* d_w, size_t n, size_t n_dst, const host::Fr& gamma, hipStream_t st);
 int quotient_large(QuotLargeArgs A, const host::Fr& root4n, const host::Fr& beta, const host::Fr& gamma, hipStream_t st);
 int quotient_mid(QuotMidArgs A, const host::Fr& alpha, const host::Fr& alpha_base, hipStream_t st);
+int quotient_bool(QuotBoolArgs A, const host::Fr& c_left, const host::Fr& c_right, const host::Fr& c_out, hipStream_t st);
 int divide_by_pseudo_vanishing(uint64_t* d_coeffs, int log2n, int log2N, hipStream_t st);
 int lagrange_l1_fft(uint64_t* d_l1, uint64_t* d_tmp, int log2n, int log2N, Scratch& S, hipStream_t st);
 int lincomb(LinCombArgs A, const host::Fr* coeffs, hipStream_t st);

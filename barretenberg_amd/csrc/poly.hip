@@ -575,6 +575,18 @@ __global__ void __launch_bounds__(PT) k_quotient_mid(QuotMidArgs A)
     stv(A.q, i, add(add(add(t6, t4), add(g3, g2)), gc));
 }
 
+// bool_widget.cpp:62-100: q[i] += c_l q_bl (w_l^2 - w_l) + c_r q_br (w_r^2 - w_r) + c_o q_bo (w_o^2 - w_o), wires at index 2i
+__global__ void __launch_bounds__(PT) k_quotient_bool(QuotBoolArgs A)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n2) return;
+    const FrV wl = ldv(A.wl_f, 2 * i), wr = ldv(A.wr_f, 2 * i), wo = ldv(A.wo_f, 2 * i);
+    auto tl = mul(mul(weak(sub(mulv(wl, wl), wl)), ldv(A.qbl_f, i)), cst(A.cl_fix_m261));
+    auto tr = mul(mul(weak(sub(mulv(wr, wr), wr)), ldv(A.qbr_f, i)), cst(A.cr_fix_m261));
+    auto to = mul(mul(weak(sub(mulv(wo, wo), wo)), ldv(A.qbo_f, i)), cst(A.co_fix_m261));
+    stv(A.q, i, add(add(add(tl, tr), to), ldv(A.q, i)));
+}
+
 // polynomial_arithmetic.cpp:478-560: c[i] *= (x_i - w_n^-1) / ((x_i)^n - 1),  x_i = g w_N^i;  (x_i)^n - 1 takes k = N/n values
 __global__ void __launch_bounds__(PT) k_divide_vanishing(uint32_t* __restrict__ c, uint32_t N, uint32_t k, PowTab root, Limbs9 g_m261, Limbs9 step_m261,
                                                        Limbs9 wninv_m261, Limbs9 inv0, Limbs9 inv1, Limbs9 inv2, Limbs9 inv3)
@@ -963,6 +975,17 @@ int quotient_mid(QuotMidArgs A, const host::Fr& alpha, const host::Fr& alpha_bas
     A.abase_fix2_m261 = host::limbs_m261(host::fr_mul(alpha_base, f2));
     A.abase_fix3_m261 = host::limbs_m261(host::fr_mul(alpha_base, f3));
     k_quotient_mid<<<pw_blocks(A.n2), PT, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
+    return BBGPU_OK;
+}
+
+int quotient_bool(QuotBoolArgs A, const host::Fr& c_left, const host::Fr& c_right, const host::Fr& c_out, hipStream_t st)
+{
+    const host::Fr f2 = host::fr_from_u64(32);
+    A.cl_fix_m261 = host::limbs_m261(host::fr_mul(c_left, f2));
+    A.cr_fix_m261 = host::limbs_m261(host::fr_mul(c_right, f2));
+    A.co_fix_m261 = host::limbs_m261(host::fr_mul(c_out, f2));
+    k_quotient_bool<<<pw_blocks(A.n2), PT, 0, st>>>(A);
     HIPCHK(hipGetLastError());
     return BBGPU_OK;
 }

@@ -17,6 +17,7 @@ LEFT, RIGHT, OUTPUT = 0, 1 << 30, 1 << 31  # ComposerBase::WireType, composer_ba
 
 PROOF_POINTS = ["W_L", "W_R", "W_O", "Z_1", "T_LO", "T_MID", "T_HI", "PI_Z", "PI_Z_OMEGA"]
 VK_POINTS = ["SIGMA_1", "SIGMA_2", "SIGMA_3", "Q_M", "Q_L", "Q_R", "Q_O", "Q_C"]
+VK_POINTS_BOOL = VK_POINTS + ["Q_BL", "Q_BR", "Q_BO"]
 PROOF_EVALS = ["w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval"]
 
 
@@ -102,6 +103,68 @@ class StandardComposer:
         }
 
 
+class BoolComposer(StandardComposer):
+    """waffle::BoolComposer (composer/bool_composer.hpp:8-46, bool_composer.cpp:13-143): boolean constraints are not gates of their
+    own but selectors q_bl / q_br / q_bo on the wires of the existing gates, checked by the bool widget next to the arithmetic one"""
+
+    def __init__(self):
+        super().__init__()
+        self.is_bool = []
+        self.zero_idx = self.add_variable(0)  # bool_composer.hpp:16
+
+    def add_variable(self, value):
+        self.is_bool.append(False)
+        return super().add_variable(value)
+
+    # bool_composer.cpp:23-29
+    def create_bool_gate(self, a):
+        self.is_bool[a] = True
+
+    # bool_composer.cpp:68-143 (process_bool_gates + preprocess)
+    def preprocess(self):
+        n = self.n
+        log2_n = (n + 1).bit_length() - 1
+        if (1 << log2_n) != n + 1:
+            log2_n += 1
+        new_n = 1 << log2_n
+        pad = new_n - n
+        qb = [[1 if self.is_bool[w[i]] else 0 for i in range(n)] + [0] * pad for w in (self.w_l, self.w_r, self.w_o)]
+        w_l = self.w_l + [self.zero_idx] * pad
+        w_r = self.w_r + [self.zero_idx] * pad
+        w_o = self.w_o + [self.zero_idx] * pad
+        sel = [q + [0] * pad for q in (self.q_m, self.q_l, self.q_r, self.q_o, self.q_c)]
+        sigma = [np.arange(new_n, dtype=np.uint32) + np.uint32(t) for t in (LEFT, RIGHT, OUTPUT)]
+        for cyc in self.wire_epicycles:
+            for j, (gate, wire) in enumerate(cyc):
+                nxt_gate, nxt_wire = cyc[0] if j == len(cyc) - 1 else cyc[j + 1]
+                sigma[wire >> 30][gate] = np.uint32((nxt_gate + nxt_wire) & 0xFFFFFFFF)
+        v = self.variables
+        return {
+            "n": new_n,
+            "w_l": to_montgomery_limbs([v[i] for i in w_l]), "w_r": to_montgomery_limbs([v[i] for i in w_r]),
+            "w_o": to_montgomery_limbs([v[i] for i in w_o]),
+            "sigma_1_mapping": sigma[0], "sigma_2_mapping": sigma[1], "sigma_3_mapping": sigma[2],
+            "q_m": to_montgomery_limbs(sel[0]), "q_l": to_montgomery_limbs(sel[1]), "q_r": to_montgomery_limbs(sel[2]),
+            "q_o": to_montgomery_limbs(sel[3]), "q_c": to_montgomery_limbs(sel[4]),
+            "q_bl": to_montgomery_limbs(qb[0]), "q_br": to_montgomery_limbs(qb[1]), "q_bo": to_montgomery_limbs(qb[2]),
+        }
+
+
+def bool_circuit(num_gates):
+    """the BoolComposer fixture circuit of oracle/plonk_driver.cpp (BB_CIRCUIT=bool): num_gates / 2 pairs of bits a, b constrained
+    boolean, c = a b (mul gate), d = a + c (add gate)"""
+    composer = BoolComposer()
+    for i in range(num_gates // 2):
+        abit, bbit = ((i * 7 + 1) >> 1) & 1, ((i * 5 + 3) >> 2) & 1
+        a, b = composer.add_variable(abit), composer.add_variable(bbit)
+        c, d = composer.add_variable(abit & bbit), composer.add_variable(abit + (abit & bbit))
+        composer.create_bool_gate(a)
+        composer.create_bool_gate(b)
+        composer.create_mul_gate(a, b, c, 1, -1, 0)
+        composer.create_add_gate(a, c, d, 1, 1, -1, 0)
+    return composer
+
+
 class field_t:
     """plonk::stdlib::field_t: value = multiplicative_constant * witness + additive_constant (field.tcc:11-37)"""
 
@@ -173,7 +236,7 @@ def bench_circuit(num_gates, a0, b0):
 
 class _Circuit(C.Structure):
     _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in ("w_l", "w_r", "w_o", "sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping",
-                                                               "q_m", "q_l", "q_r", "q_o", "q_c")]
+                                                               "q_m", "q_l", "q_r", "q_o", "q_c", "q_bl", "q_br", "q_bo")]
 
 
 class Prover:
@@ -209,10 +272,10 @@ class Prover:
 
     def preprocess(self):
         """waffle::preprocess(prover): -> dict of the eight verification-key commitments, each (8,) uint64 affine"""
-        out = np.zeros(64, dtype=np.uint64)
+        out = np.zeros(88, dtype=np.uint64)
         self.gpu.lib.bbgpu_plonk_preprocess.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
         self.gpu._chk(self.gpu.lib.bbgpu_plonk_preprocess(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))))
-        return {k: out[8 * i:8 * i + 8] for i, k in enumerate(VK_POINTS)}
+        return {k: out[8 * i:8 * i + 8] for i, k in enumerate(VK_POINTS_BOOL if "q_bl" in self._keep else VK_POINTS)}
 
     def challenges(self):
         out = np.zeros(20, dtype=np.uint64)

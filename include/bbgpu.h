@@ -172,6 +172,9 @@ typedef struct {
     const uint64_t *w_l, *w_r, *w_o;                                   /* n x 4 limbs each */
     const uint32_t *sigma_1_mapping, *sigma_2_mapping, *sigma_3_mapping; /* n each */
     const uint64_t *q_m, *q_l, *q_r, *q_o, *q_c;                       /* n x 4 limbs each */
+    /* optional second widget, all three or none (NULL): the boolean-constraint selectors BoolComposer::preprocess() hands
+     * ProverBoolWidget (bool_composer.cpp:68-143, widgets/bool_widget.hpp): q_bl, q_br, q_bo, n x 4 limbs each */
+    const uint64_t *q_bl, *q_br, *q_bo;
 } bbgpu_plonk_circuit;
 /* proof = waffle::plonk_proof (waffle_types.hpp:18-45) as filled for this circuit: W_L, W_R, W_O, Z_1, T_LO, T_MID, T_HI,
  * PI_Z, PI_Z_OMEGA (affine x, y: 8 limbs each), then w_l_eval, w_r_eval, w_o_eval, sigma_1_eval, sigma_2_eval,
@@ -180,9 +183,11 @@ typedef struct {
 int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* circuit, int srs_handle); /* returns a prover handle >= 0 */
 int bbgpu_plonk_prover_set_witness(int prover, const uint64_t* w_l, const uint64_t* w_r, const uint64_t* w_o);
 int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF_WORDS]); /* Prover::construct_proof, prover.cpp:661-670 */
-/* waffle::preprocess(prover) (preprocess.hpp:16-55, arithmetic_widget.cpp:128-157): the verification key of the circuit --
- * SIGMA_1, SIGMA_2, SIGMA_3, then the commitments to q_m, q_l, q_r, q_o, q_c (affine x, y: 8 limbs each) */
-int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[64]);
+/* waffle::preprocess(prover) (preprocess.hpp:16-55, arithmetic_widget.cpp:128-157, bool_widget.cpp:118-152): the verification key of
+ * the circuit -- SIGMA_1, SIGMA_2, SIGMA_3, the commitments to q_m, q_l, q_r, q_o, q_c, and with the bool widget those to q_bl, q_br,
+ * q_bo (affine x, y: 8 limbs each; 8 or 11 points -- pass room for 11) */
+#define BBGPU_PLONK_VK_WORDS 88
+int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[BBGPU_PLONK_VK_WORDS]);
 int bbgpu_plonk_last_challenges(int prover, uint64_t out[20]); /* beta, gamma, alpha, z, nu (waffle_types.hpp:9-16) */
 int bbgpu_plonk_last_timing(int prover, double ms_out[4]);     /* construct_proof wall ms: total, in commitments, rest, first-use preparation */
 int bbgpu_plonk_prover_destroy(int prover);

@@ -17,17 +17,21 @@
 //   plonk_xxx dump <num_gates> <path>          write the waffle::Prover INPUT state the composer produced (witness values,
 //                                              sigma mappings, selector values) as a flat binary file: the input of the native
 //                                              resident prover (bbgpu_plonk_*), so that it proves the very same circuit
+//   BB_CIRCUIT=bool in the environment switches every mode to a BoolComposer circuit (arithmetic + bool widget): <num_gates> / 2 pairs of
+//   bits a_i, b_i constrained boolean, c_i = a_i b_i (mul gate), d_i = a_i + c_i (add gate)
 //   plonk_xxx verify <num_gates> < proof       rebuild the same circuit's Verifier and check a proof given in the `prove` text
 //                                              format on stdin (used to verify proofs made by the native GPU prover)
 #include <barretenberg/curves/bn254/fq.hpp>
 #include <barretenberg/curves/bn254/fr.hpp>
 #include <barretenberg/curves/bn254/g1.hpp>
 #include <barretenberg/curves/bn254/g2.hpp>
+#include <barretenberg/waffle/composer/bool_composer.hpp>
 #include <barretenberg/waffle/composer/standard_composer.hpp>
 #include <barretenberg/waffle/proof_system/preprocess.hpp>
 #include <barretenberg/waffle/proof_system/prover/prover.hpp>
 #include <barretenberg/waffle/proof_system/verifier/verifier.hpp>
 #include <barretenberg/waffle/proof_system/widgets/arithmetic_widget.hpp>
+#include <barretenberg/waffle/proof_system/widgets/bool_widget.hpp>
 #include <barretenberg/waffle/stdlib/field/field.hpp>
 
 #include <arpa/inet.h>
@@ -35,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 using namespace barretenberg;
@@ -92,12 +97,12 @@ void hex4(const char* name, const uint64_t* d)
 }
 
 void build_circuit(waffle::StandardComposer& composer, size_t num_gates);
+std::unique_ptr<waffle::ComposerBase> make_circuit(size_t num_gates);
 
 int prove(size_t num_gates, bool trace)
 {
-    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
-    build_circuit(composer, num_gates);
-    waffle::Prover prover = composer.preprocess();
+    std::unique_ptr<waffle::ComposerBase> composer = make_circuit(num_gates);
+    waffle::Prover prover = composer->preprocess();
     waffle::Verifier verifier = waffle::preprocess(prover);
     auto t0 = std::chrono::steady_clock::now();
     waffle::plonk_proof proof = prover.construct_proof();
@@ -145,15 +150,43 @@ void build_circuit(waffle::StandardComposer& composer, size_t num_gates)
     }
 }
 
+// BoolComposer circuit (bool_composer.cpp): bits with boolean constraints, products and sums of them
+void build_bool_circuit(waffle::BoolComposer& composer, size_t num_gates)
+{
+    const fr::field_t one = fr::one, zero = fr::zero, minus_one = fr::neg_one();
+    for (size_t i = 0; i < num_gates / 2; ++i) {
+        const bool abit = ((i * 7 + 1) >> 1) & 1, bbit = ((i * 5 + 3) >> 2) & 1;
+        const uint32_t a = composer.add_variable(abit ? one : zero), b = composer.add_variable(bbit ? one : zero);
+        const uint32_t c = composer.add_variable((abit && bbit) ? one : zero);
+        const uint32_t d = composer.add_variable(fr::add(abit ? one : zero, (abit && bbit) ? one : zero));
+        composer.create_bool_gate(a);
+        composer.create_bool_gate(b);
+        composer.create_mul_gate({ a, b, c, one, minus_one, zero });
+        composer.create_add_gate({ a, c, d, one, one, minus_one, zero });
+    }
+}
+std::unique_ptr<waffle::ComposerBase> make_circuit(size_t num_gates)
+{
+    const char* kind = getenv("BB_CIRCUIT");
+    if (kind && !strcmp(kind, "bool")) {
+        auto c = std::make_unique<waffle::BoolComposer>(num_gates);
+        build_bool_circuit(*c, num_gates);
+        return c;
+    }
+    auto c = std::make_unique<waffle::StandardComposer>(num_gates);
+    build_circuit(*c, num_gates);
+    return c;
+}
+
 void wr(FILE* f, const void* p, size_t bytes) { if (fwrite(p, 1, bytes, f) != bytes) abort(); }
 
 int dump(size_t num_gates, const char* path)
 {
-    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
-    build_circuit(composer, num_gates);
-    waffle::Prover prover = composer.preprocess();
+    std::unique_ptr<waffle::ComposerBase> composer = make_circuit(num_gates);
+    waffle::Prover prover = composer->preprocess();
     const waffle::ProverArithmeticWidget* w = dynamic_cast<const waffle::ProverArithmeticWidget*>(prover.widgets[0].get());
-    if (!w || prover.widgets.size() != 1) return 3;
+    const waffle::ProverBoolWidget* wb = prover.widgets.size() > 1 ? dynamic_cast<const waffle::ProverBoolWidget*>(prover.widgets[1].get()) : nullptr;
+    if (!w || prover.widgets.size() > 2 || (prover.widgets.size() == 2 && !wb)) return 3;
     FILE* f = fopen(path, "wb");
     if (!f) return 1;
     const uint64_t n = prover.n;
@@ -165,6 +198,10 @@ int dump(size_t num_gates, const char* path)
     for (auto* m : maps) wr(f, m->data(), n * 4);
     const barretenberg::polynomial* sel[5] = { &w->q_m, &w->q_l, &w->q_r, &w->q_o, &w->q_c };
     for (auto* p : sel) wr(f, const_cast<barretenberg::polynomial*>(p)->get_coefficients(), n * 32);
+    if (wb) { // bool widget selectors follow (bool_widget.hpp)
+        const barretenberg::polynomial* bsel[3] = { &wb->q_bl, &wb->q_br, &wb->q_bo };
+        for (auto* p : bsel) wr(f, const_cast<barretenberg::polynomial*>(p)->get_coefficients(), n * 32);
+    }
     fclose(f);
     printf("n %zu\n", (size_t)n);
     return 0;
@@ -172,9 +209,8 @@ int dump(size_t num_gates, const char* path)
 
 int vk(size_t num_gates)
 {
-    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
-    build_circuit(composer, num_gates);
-    waffle::Prover prover = composer.preprocess();
+    std::unique_ptr<waffle::ComposerBase> composer = make_circuit(num_gates);
+    waffle::Prover prover = composer->preprocess();
     waffle::Verifier verifier = waffle::preprocess(prover);
     printf("n %zu\n", prover.n);
     const g1::affine_element* pts[3] = { &verifier.SIGMA_1, &verifier.SIGMA_2, &verifier.SIGMA_3 };
@@ -189,6 +225,14 @@ int vk(size_t num_gates)
     for (int i = 0; i < 5; i++) {
         snprintf(nm, sizeof nm, "%s.x", qn[i]); hex4(nm, inst[i].x.data);
         snprintf(nm, sizeof nm, "%s.y", qn[i]); hex4(nm, inst[i].y.data);
+    }
+    if (verifier.verifier_widgets.size() > 1) { // bool widget: commitments to q_bl, q_br, q_bo (bool_widget.cpp:118-152)
+        const char* bn[3] = { "Q_BL", "Q_BR", "Q_BO" };
+        const auto& binst = verifier.verifier_widgets[1]->instance;
+        for (int i = 0; i < 3; i++) {
+            snprintf(nm, sizeof nm, "%s.x", bn[i]); hex4(nm, binst[i].x.data);
+            snprintf(nm, sizeof nm, "%s.y", bn[i]); hex4(nm, binst[i].y.data);
+        }
     }
     return 0;
 }
@@ -208,9 +252,8 @@ bool rd4(const char* want, uint64_t* d)
 
 int verify(size_t num_gates)
 {
-    waffle::StandardComposer composer = waffle::StandardComposer(num_gates);
-    build_circuit(composer, num_gates);
-    waffle::Prover prover = composer.preprocess();
+    std::unique_ptr<waffle::ComposerBase> composer = make_circuit(num_gates);
+    waffle::Prover prover = composer->preprocess();
     waffle::Verifier verifier = waffle::preprocess(prover);
     waffle::plonk_proof proof;
     g1::affine_element* pts[9] = { &proof.W_L, &proof.W_R, &proof.W_O, &proof.Z_1, &proof.T_LO, &proof.T_MID, &proof.T_HI, &proof.PI_Z, &proof.PI_Z_OMEGA };

@@ -264,3 +264,37 @@ def test_resident_prover_on_a_transcript_file(gpu, golden, tmp_path):
         finally:
             prover.destroy()
     gpu.srs_release(h)
+
+
+@pytest.mark.parametrize("gates", [64, 4096])
+def test_resident_prover_with_bool_widget(gpu, srs65536, golden, gates):
+    """second widget of the chain: a BoolComposer circuit (arithmetic + bool widget, bool_widget.cpp) -- proof bytes, all five challenges and
+    the verification key (11 commitments) equal the reference's; its Verifier accepts the proof"""
+    from barretenberg_amd.plonk import VK_POINTS_BOOL, Prover, bool_circuit, hex4, proof_lines
+    from oracle.pyoracle import Oracle
+    fx = golden("plonk_trace.json")["bool"]
+    state = bool_circuit(gates).preprocess()
+    prover = Prover(gpu, state, srs65536)
+    try:
+        proof = prover.construct_proof()
+        got = proof_lines(state["n"], proof)
+        ch = prover.challenges()
+        for name in ("gamma", "beta", "alpha", "z", "nu"):
+            assert hx(ch[name])[0] == fx["challenges"][str(gates)][name], name
+        assert got == fx["proofs"][str(gates)][:26]
+        vk = prover.preprocess()
+        ref = {ln.split()[0]: ln.split()[1] for ln in fx["verification_keys"][str(gates)][1:]}
+        for k in VK_POINTS_BOOL:
+            if int(vk[k][7]) >> 63:  # commitment to a zero selector (no boolean output wires here): see the arithmetic-widget test
+                rp = np.array([int(ref[k + c][16 * (3 - j):16 * (4 - j)], 16) for c in (".x", ".y") for j in range(4)], dtype=np.uint64)
+                assert not Oracle().g1_on_curve(rp), k
+                continue
+            assert hex4(vk[k][0:4]) == ref[k + ".x"] and hex4(vk[k][4:8]) == ref[k + ".y"], k
+        assert np.array_equal(prover.construct_proof(), proof)
+        exe = os.path.join(ROOT, "oracle", "_ref", "plonk_cpu")
+        if os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "transcript.dat")):
+            r = subprocess.run([exe, "verify", str(gates)], input="\n".join(got) + "\n", cwd=ROOT, capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, OMP_NUM_THREADS="16", BB_CIRCUIT="bool"))
+            assert r.returncode == 0 and r.stdout.strip() == "verified 1", (r.stdout, r.stderr[-500:])
+    finally:
+        prover.destroy()

@@ -59,3 +59,15 @@ def test_transcript_challenges_match_reference(golden, trace, gates):
     for i, name in enumerate(("gamma", "beta", "alpha", "z")):
         got = "%016x%016x%016x%016x" % tuple(int(v) for v in out[4 * i:4 * i + 4][::-1])
         assert got == want[name], name
+
+
+@pytest.mark.parametrize("gates", [64, 4096])
+def test_bool_composer_mirror_digests(trace, gates):
+    """BoolComposer mirror (bool_composer.cpp:68-143) vs the reference composer's Prover state, SHA-256 of all fourteen arrays"""
+    from barretenberg_amd.plonk import bool_circuit
+    st = bool_circuit(gates).preprocess()
+    want = trace["bool"]["input_digests"][str(gates)]
+    assert st["n"] == want["n"]
+    for k, d in want.items():
+        if k != "n":
+            assert hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() == d, k

@@ -68,6 +68,29 @@ def main():
             out["input_state_32"] = {k: [["%016x" % int(v) for v in row] for row in st[k]] for k in FIELDS64 + SELECTORS}
             out["input_state_32"].update({k: [int(v) for v in st[k]] for k in MAPS})
         os.remove(path)
+    # BoolComposer circuit (arithmetic + bool widget; `BB_CIRCUIT=bool plonk_cpu ...`): proofs, challenges, verification keys, input digests
+    benv = dict(os.environ, BB_CIRCUIT="bool")
+    bsel = SELECTORS + ("q_bl", "q_br", "q_bo")
+    out["bool"] = {"proofs": {}, "challenges": {}, "verification_keys": {}, "input_digests": {}}
+    for gates in (64, 4096):
+        lines = subprocess.run([EXE, "trace", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True, env=benv).stdout.strip().split("\n")
+        out["bool"]["challenges"][str(gates)] = {ln.split()[0]: ln.split()[1] for ln in lines if ln.split()[0] in ("beta", "gamma", "alpha", "z", "nu")}
+        out["bool"]["proofs"][str(gates)] = [ln for ln in lines if ln.split()[0] not in ("beta", "gamma", "alpha", "z", "nu")]
+        out["bool"]["verification_keys"][str(gates)] = subprocess.run([EXE, "vk", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True,
+                                                                      env=benv).stdout.strip().split("\n")
+        path = "/tmp/plonk_dump_bool_%d.bin" % gates
+        subprocess.run([EXE, "dump", str(gates), path], cwd=ROOT, check=True, stdout=subprocess.DEVNULL, env=benv)
+        b = open(path, "rb").read()
+        n = int.from_bytes(b[8:16], "little")
+        o, dig = 16, {"n": n}
+        for k in FIELDS64:
+            dig[k] = hashlib.sha256(b[o:o + 32 * n]).hexdigest(); o += 32 * n
+        for k in MAPS:
+            dig[k] = hashlib.sha256(b[o:o + 4 * n]).hexdigest(); o += 4 * n
+        for k in bsel:
+            dig[k] = hashlib.sha256(b[o:o + 32 * n]).hexdigest(); o += 32 * n
+        out["bool"]["input_digests"][str(gates)] = dig
+        os.remove(path)
     if not big:  # keep the large-circuit entries of an earlier run
         old = json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_trace.json")))
         for key in ("challenges", "input_digests", "verification_keys"):
