@@ -155,7 +155,7 @@ def bool_circuit(num_gates):
     boolean, c = a b (mul gate), d = a + c (add gate)"""
     composer = BoolComposer()
     for i in range(num_gates // 2):
-        abit, bbit = ((i * 7 + 1) >> 1) & 1, ((i * 5 + 3) >> 2) & 1
+        abit, bbit = (i * 7 + 1) & 1, ((i * 5 + 3) >> 1) & 1
         a, b = composer.add_variable(abit), composer.add_variable(bbit)
         c, d = composer.add_variable(abit & bbit), composer.add_variable(abit + (abit & bbit))
         composer.create_bool_gate(a)

@@ -155,7 +155,7 @@ void build_bool_circuit(waffle::BoolComposer& composer, size_t num_gates)
 {
     const fr::field_t one = fr::one, zero = fr::zero, minus_one = fr::neg_one();
     for (size_t i = 0; i < num_gates / 2; ++i) {
-        const bool abit = ((i * 7 + 1) >> 1) & 1, bbit = ((i * 5 + 3) >> 2) & 1;
+        const bool abit = (i * 7 + 1) & 1, bbit = ((i * 5 + 3) >> 1) & 1; // pair 0 is (1, 1): no all-zero wire polynomial even at n = 4
         const uint32_t a = composer.add_variable(abit ? one : zero), b = composer.add_variable(bbit ? one : zero);
         const uint32_t c = composer.add_variable((abit && bbit) ? one : zero);
         const uint32_t d = composer.add_variable(fr::add(abit ? one : zero, (abit && bbit) ? one : zero));

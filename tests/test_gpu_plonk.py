@@ -266,10 +266,11 @@ def test_resident_prover_on_a_transcript_file(gpu, golden, tmp_path):
     gpu.srs_release(h)
 
 
-@pytest.mark.parametrize("gates", [64, 4096])
+@pytest.mark.parametrize("gates", [2, 6, 14, 64, 4096])
 def test_resident_prover_with_bool_widget(gpu, srs65536, golden, gates):
     """second widget of the chain: a BoolComposer circuit (arithmetic + bool widget, bool_widget.cpp) -- proof bytes, all five challenges and
-    the verification key (11 commitments) equal the reference's; its Verifier accepts the proof"""
+    the verification key (11 commitments) equal the reference's; its Verifier accepts the proof.  gates = 2, 6, 14 are circuits of
+    n = 4, 8, 16: the smallest proofs the reference's own tests make (test_verifier.cpp:105-122) -- 4-point MSMs, 4/8/16-point transforms."""
     from barretenberg_amd.plonk import VK_POINTS_BOOL, Prover, bool_circuit, hex4, proof_lines
     from oracle.pyoracle import Oracle
     fx = golden("plonk_trace.json")["bool"]

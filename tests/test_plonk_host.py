@@ -61,7 +61,7 @@ def test_transcript_challenges_match_reference(golden, trace, gates):
         assert got == want[name], name
 
 
-@pytest.mark.parametrize("gates", [64, 4096])
+@pytest.mark.parametrize("gates", [2, 6, 14, 64, 4096])
 def test_bool_composer_mirror_digests(trace, gates):
     """BoolComposer mirror (bool_composer.cpp:68-143) vs the reference composer's Prover state, SHA-256 of all fourteen arrays"""
     from barretenberg_amd.plonk import bool_circuit

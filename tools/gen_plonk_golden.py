@@ -72,7 +72,7 @@ def main():
     benv = dict(os.environ, BB_CIRCUIT="bool")
     bsel = SELECTORS + ("q_bl", "q_br", "q_bo")
     out["bool"] = {"proofs": {}, "challenges": {}, "verification_keys": {}, "input_digests": {}}
-    for gates in (64, 4096):
+    for gates in (2, 6, 14, 64, 4096):  # n = 4, 8, 16 (the reference's own smallest proofs, test_verifier.cpp:105-122), 128, 8192
         lines = subprocess.run([EXE, "trace", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True, env=benv).stdout.strip().split("\n")
         out["bool"]["challenges"][str(gates)] = {ln.split()[0]: ln.split()[1] for ln in lines if ln.split()[0] in ("beta", "gamma", "alpha", "z", "nu")}
         out["bool"]["proofs"][str(gates)] = [ln for ln in lines if ln.split()[0] not in ("beta", "gamma", "alpha", "z", "nu")]
