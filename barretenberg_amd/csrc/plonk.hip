@@ -59,6 +59,7 @@ double now_ms()
 struct Proof {
     uint64_t W_L[8], W_R[8], W_O[8], Z_1[8], T_LO[8], T_MID[8], T_HI[8], PI_Z[8], PI_Z_OMEGA[8];
     Fr w_l_eval, w_r_eval, w_o_eval, sigma_1_eval, sigma_2_eval, z_1_shifted_eval, linear_eval;
+    Fr w_l_shifted_eval, w_r_shifted_eval, w_o_shifted_eval, q_c_eval, q_mimc_coefficient_eval; // widget-dependent (waffle_types.hpp:39-43)
 };
 static_assert(sizeof(Proof) == BBGPU_PLONK_PROOF_WORDS * 8, "proof layout");
 
@@ -91,6 +92,11 @@ class PlonkProver {
     uint64_t* qb_lagrange[3] = {};
     uint64_t* qb_coeff[3] = {};
     uint64_t* qb_fft2n[3] = {};
+    // optional MiMC widget (mimc_widget.hpp): [0] = q_mimc_selector, [1] = q_mimc_coefficient
+    bool has_mimc = false;
+    uint64_t* qm_lagrange[2] = {};
+    uint64_t* qm_coeff[2] = {};
+    uint64_t* qm_fft4n[2] = {};
     // per proof
     uint64_t* w[3] = {};        // wire polynomials, coefficient form          (Prover::w_l, w_r, w_o after :130-132)
     uint64_t* sigma[3] = {};    // beta * sigma_i, coefficient form             (after :245-247)
@@ -178,6 +184,19 @@ class PlonkProver {
                 qb_coeff[k] = qb_coeff[0] + (size_t)k * n * 4;
                 qb_fft2n[k] = qb_fft2n[0] + (size_t)k * 2 * n * 4;
                 HIPCHK(hipMemcpy(qb_lagrange[k], hb[k], fb, hipMemcpyHostToDevice));
+            }
+        }
+        const uint64_t* hmm[2] = { c->q_mimc_selector, c->q_mimc_coefficient };
+        has_mimc = hmm[0] != nullptr;
+        if (has_mimc) {
+            RC(dalloc(&qm_lagrange[0], 2 * fb));
+            RC(dalloc(&qm_coeff[0], 2 * fb));
+            RC(dalloc(&qm_fft4n[0], 8 * fb));
+            for (int k = 0; k < 2; k++) {
+                qm_lagrange[k] = qm_lagrange[0] + (size_t)k * n * 4;
+                qm_coeff[k] = qm_coeff[0] + (size_t)k * n * 4;
+                qm_fft4n[k] = qm_fft4n[0] + (size_t)k * 4 * n * 4;
+                HIPCHK(hipMemcpy(qm_lagrange[k], hmm[k], fb, hipMemcpyHostToDevice));
             }
         }
         RC(dalloc(&roots, fb));
@@ -289,6 +308,12 @@ class PlonkProver {
             for (int k = 0; k < 3; k++) RC(poly::copy_pad(qb_fft2n[k], qb_coeff[k], n, 2 * n, st));
             RC(ntt_batch(qb_fft2n[0], 2 * n, 3, BBGPU_COSET_FFT));
         }
+        if (has_mimc) { // mimc_widget.cpp:60-67 without the alpha scaling (applied in quotient_mimc)
+            RC(copy(qm_coeff[0], qm_lagrange[0], 2 * n));
+            RC(ntt_batch(qm_coeff[0], n, 2, BBGPU_IFFT));
+            for (int k = 0; k < 2; k++) RC(poly::copy_pad(qm_fft4n[k], qm_coeff[k], n, 4 * n, st));
+            RC(ntt_batch(qm_fft4n[0], 4 * n, 2, BBGPU_COSET_FFT));
+        }
         RC(poly::lagrange_l1_fft(l_1, quotient_mid, log2n, log2n + 1, scratch, st)); // prover.cpp:350-351 (quotient_mid as workspace)
         HIPCHK(hipStreamSynchronize(st));
         circuit_ready = true;
@@ -391,6 +416,14 @@ class PlonkProver {
             Bq.n2 = (uint32_t)n2;
             RC(poly::quotient_bool(Bq, a5, a6, a7, st));
         }
+        if (has_mimc) { // second widget of a MiMCComposer circuit: alpha_base * alpha from the arithmetic widget, alpha_step = alpha
+            poly::QuotMimcArgs Mq{};
+            Mq.wl_f = L.wl_f; Mq.wr_f = L.wr_f; Mq.wo_f = L.wo_f;
+            Mq.qsel_f = (const uint32_t*)qm_fft4n[0]; Mq.qcoef_f = (const uint32_t*)qm_fft4n[1];
+            Mq.q = (uint32_t*)quotient_large;
+            Mq.n4 = (uint32_t)n4;
+            RC(poly::quotient_mimc(Mq, host::fr_mul(alpha_base, challenges.alpha), challenges.alpha, st));
+        }
         return BBGPU_OK;
     }
     // prover.cpp:405-465 (after the wire / Z parts above)
@@ -436,14 +469,21 @@ class PlonkProver {
         const Fr shifted_z = host::fr_mul(zc, host::fr_root_of_unity(log2n));
         // seven evaluations, one read-back (:478-480, :504-506, :512)
         const Fr zs[2] = { zc, shifted_z };
-        const poly::EvalJob ej[7] = { { w[0], n, 0, slots + 0 * 4 }, { w[1], n, 0, slots + 1 * 4 }, { w[2], n, 0, slots + 2 * 4 },
+        const poly::EvalJob ej[9] = { { w[0], n, 0, slots + 0 * 4 }, { w[1], n, 0, slots + 1 * 4 }, { w[2], n, 0, slots + 2 * 4 },
                                       { sigma[0], n, 0, slots + 3 * 4 }, { sigma[1], n, 0, slots + 4 * 4 }, { z, n, 1, slots + 5 * 4 },
-                                      { quotient_large, 3 * n, 0, slots + 6 * 4 } };
-        RC(poly::evaluate_batch_to_device(ej, 7, zs, scratch, st));
-        HIPCHK(hipMemcpyAsync(h_slots, slots, 7 * 32, hipMemcpyDeviceToHost, st));
+                                      { quotient_large, 3 * n, 0, slots + 6 * 4 },
+                                      // MiMC widget: REQUIRES_W_O_SHIFTED (prover.cpp:499-502) and compute_proof_elements (mimc_widget.cpp:92-95)
+                                      { w[2], n, 1, slots + 7 * 4 }, { qm_coeff[1], n, 0, slots + 8 * 4 } };
+        const int nev = has_mimc ? 9 : 7;
+        RC(poly::evaluate_batch_to_device(ej, nev, zs, scratch, st));
+        HIPCHK(hipMemcpyAsync(h_slots, slots, (size_t)nev * 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        Fr ev[7];
-        memcpy(ev, h_slots, sizeof ev);
+        Fr ev[9];
+        memcpy(ev, h_slots, (size_t)nev * 32);
+        if (has_mimc) {
+            proof.w_o_shifted_eval = ev[7];
+            proof.q_mimc_coefficient_eval = ev[8];
+        }
         proof.w_l_eval = ev[0];
         proof.w_r_eval = ev[1];
         proof.w_o_eval = ev[2];
@@ -477,12 +517,23 @@ class PlonkProver {
         const Fr cs[10] = { lt_z1, host::fr_mul(lt_sigma3, beta_inv), host::fr_mul(w_lr, alpha4), host::fr_mul(proof.w_l_eval, alpha4),
                             host::fr_mul(proof.w_r_eval, alpha4), host::fr_mul(proof.w_o_eval, alpha4), alpha4,
                             boolmul(proof.w_l_eval, alpha5), boolmul(proof.w_r_eval, alpha6), boolmul(proof.w_o_eval, alpha7) };
-        const int terms = has_bool ? 10 : 7;
-        for (int j = 0; j < terms; j++) A.p[j] = (const uint32_t*)ps[j];
+        int terms = has_bool ? 10 : 7;
+        const uint64_t* psm[8];
+        Fr csm[8];
+        if (has_mimc) { // mimc_widget.cpp:97-113 with alpha_base = alpha^5, alpha_step = alpha
+            const Fr t0 = host::fr_add(host::fr_add(proof.w_o_eval, proof.w_l_eval), proof.q_mimc_coefficient_eval);
+            const Fr a = host::fr_sub(host::fr_mul(host::fr_sqr(t0), t0), proof.w_r_eval);
+            const Fr b = host::fr_mul(host::fr_sub(host::fr_mul(host::fr_sqr(proof.w_r_eval), t0), proof.w_o_shifted_eval), alpha);
+            for (int j = 0; j < 7; j++) { psm[j] = ps[j]; csm[j] = cs[j]; }
+            psm[7] = qm_coeff[0];
+            csm[7] = host::fr_mul(host::fr_add(b, a), alpha5);
+            terms = 8;
+        }
+        for (int j = 0; j < terms; j++) A.p[j] = (const uint32_t*)(has_mimc ? psm[j] : ps[j]);
         A.count = terms;
         A.out = (uint32_t*)r;
         A.n = (uint32_t)n;
-        RC(poly::lincomb(A, cs, st));
+        RC(poly::lincomb(A, has_mimc ? csm : cs, st));
         RC(poly::evaluate(r, n, zc, &proof.linear_eval, scratch, st)); // :536
         return BBGPU_OK;
     }
@@ -505,19 +556,24 @@ class PlonkProver {
         const Fr z_pow_n = host::fr_pow(challenges.z, (uint64_t)n), z_pow_2n = host::fr_pow(challenges.z, (uint64_t)2 * n);
         // :567-595 as one linear combination of nine resident vectors
         poly::LinCombArgs A{};
-        const uint64_t* ps[9] = { quotient_large, quotient_large + n * 4, quotient_large + 2 * n * 4, r, w[0], w[1], w[2], sigma[0], sigma[1] };
-        const Fr cs[9] = { host::fr_one(), z_pow_n, z_pow_2n, nu[0], nu[1], nu[2], nu[3], host::fr_mul(nu[4], beta_inv), host::fr_mul(nu[5], beta_inv) };
-        for (int j = 0; j < 9; j++) A.p[j] = (const uint32_t*)ps[j];
-        A.count = 9;
+        // with the MiMC widget: w_o joins the shifted opening at nu^8 (prover.cpp:627-635) and q_mimc_coefficient the main one at nu^9
+        // (mimc_widget.cpp:115-123)
+        const Fr nu9 = host::fr_mul(nu[7], nu[0]);
+        const uint64_t* ps[10] = { quotient_large, quotient_large + n * 4, quotient_large + 2 * n * 4, r, w[0], w[1], w[2], sigma[0], sigma[1], qm_coeff[1] };
+        const Fr cs[10] = { host::fr_one(), z_pow_n, z_pow_2n, nu[0], nu[1], nu[2], nu[3], host::fr_mul(nu[4], beta_inv), host::fr_mul(nu[5], beta_inv), nu9 };
+        const int oterms = has_mimc ? 10 : 9;
+        for (int j = 0; j < oterms; j++) A.p[j] = (const uint32_t*)ps[j];
+        A.count = oterms;
         A.out = (uint32_t*)tmp[0];
         A.n = (uint32_t)n;
         RC(poly::lincomb(A, cs, st));
         poly::LinCombArgs B{};
         B.p[0] = (const uint32_t*)z;
-        B.count = 1;
+        B.p[1] = (const uint32_t*)w[2];
+        B.count = has_mimc ? 2 : 1;
         B.out = (uint32_t*)tmp[1];
         B.n = (uint32_t)n;
-        RC(poly::lincomb(B, &nu[6], st));
+        RC(poly::lincomb(B, &nu[6], st)); // nu^7 Z (+ nu^8 w_o)
         // compute_kate_opening_coefficients (polynomial_arithmetic.cpp:562-591): W_i = sum_{j>i} F_j z^(j-i-1); the serial
         // recurrence becomes a Horner suffix scan, the remainder F(z) drops out
         const Fr shifted_z = host::fr_mul(challenges.z, host::fr_root_of_unity(log2n));
@@ -551,6 +607,10 @@ class PlonkProver {
         if (has_bool) { // bool_widget.cpp:118-152
             const uint64_t* qb[3] = { qb_coeff[0], qb_coeff[1], qb_coeff[2] };
             RC(commit(qb, 3, out + 8));
+        }
+        if (has_mimc) { // mimc_widget.cpp:125-160: q_mimc_coefficient first, then q_mimc_selector
+            const uint64_t* qmm[2] = { qm_coeff[1], qm_coeff[0] };
+            RC(commit(qmm, 2, out + 8));
         }
         return BBGPU_OK;
     }
@@ -610,6 +670,10 @@ int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* c, int srs_handle)
     }
     if ((c->q_bl != nullptr) != (c->q_br != nullptr) || (c->q_bl != nullptr) != (c->q_bo != nullptr)) {
         set_error("bool widget selectors: give all of q_bl, q_br, q_bo or none");
+        return BBGPU_ERR_ARG;
+    }
+    if ((c->q_mimc_selector != nullptr) != (c->q_mimc_coefficient != nullptr) || (c->q_mimc_selector && c->q_bl)) {
+        set_error("MiMC widget selectors: give both q_mimc_selector and q_mimc_coefficient or neither, and not together with the bool widget");
         return BBGPU_ERR_ARG;
     }
     if (c->n < 4 || (c->n & (c->n - 1)) || c->n > ((size_t)1 << 20)) {

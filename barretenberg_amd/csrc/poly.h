@@ -52,6 +52,13 @@ struct QuotBoolArgs {
     uint32_t n2;
     Limbs9 cl_fix_m261, cr_fix_m261, co_fix_m261; // alpha powers times 2^5
 };
+struct QuotMimcArgs {
+    const uint32_t *wl_f, *wr_f, *wo_f; // 4n coset evaluations
+    const uint32_t *qsel_f, *qcoef_f;   // 4n coset evaluations of q_mimc_selector / q_mimc_coefficient, unscaled
+    uint32_t* q;                        // quotient_large, accumulated into
+    uint32_t n4;
+    Limbs9 alpha_m261, abase_fix_m261;  // alpha_step; alpha_base * 2^5
+};
 struct LinCombArgs {
     const uint32_t* p[10];
     Limbs9 c[10];
@@ -68,13 +75,13 @@ struct EvalJob {
     uint64_t* d_result; // 32-byte device slot
 };
 struct EvalBatchArgs {
-    const uint32_t* c[8];
-    uint32_t* result[8];
-    uint32_t n[8], blocks[8];
-    uint8_t zsel[8];
-    Limbs9 zT[8];
+    const uint32_t* c[10];
+    uint32_t* result[10];
+    uint32_t n[10], blocks[10];
+    uint8_t zsel[10];
+    Limbs9 zT[10];
     PowTab T[2];
-    uint32_t* partial; // 8 x 256 elements
+    uint32_t* partial; // 10 x 256 elements
 };
 struct ScanJob {
     const uint64_t* in;
@@ -110,6 +117,7 @@ int z_terms(ZTermsArgs A, const host::Fr& root, const host::Fr& beta, const host
 int sigma_prepare(uint64_t* d_dst, const uint64_t* d_sigma, const uint64_t* d_w, size_t n, size_t n_dst, const host::Fr& gamma, hipStream_t st);
 int quotient_large(QuotLargeArgs A, const host::Fr& root4n, const host::Fr& beta, const host::Fr& gamma, hipStream_t st);
 int quotient_mid(QuotMidArgs A, const host::Fr& alpha, const host::Fr& alpha_base, hipStream_t st);
+int quotient_mimc(QuotMimcArgs A, const host::Fr& alpha_base, const host::Fr& alpha_step, hipStream_t st);
 int quotient_bool(QuotBoolArgs A, const host::Fr& c_left, const host::Fr& c_right, const host::Fr& c_out, hipStream_t st);
 int divide_by_pseudo_vanishing(uint64_t* d_coeffs, int log2n, int log2N, hipStream_t st);
 int lagrange_l1_fft(uint64_t* d_l1, uint64_t* d_tmp, int log2n, int log2N, Scratch& S, hipStream_t st);

@@ -575,6 +575,21 @@ __global__ void __launch_bounds__(PT) k_quotient_mid(QuotMidArgs A)
     stv(A.q, i, add(add(add(t6, t4), add(g3, g2)), gc));
 }
 
+// mimc_widget.cpp:58-90 on the 4n coset: with T0 = w_o + w_l + q_coef,
+//   q[i] += abase q_sel [ (T0^3 - w_r) + alpha (w_r^2 T0 - w_o[i + 4]) ]        (w_o[i + 4] = the next gate's output wire)
+__global__ void __launch_bounds__(PT) k_quotient_mimc(QuotMimcArgs A)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n4) return;
+    const FrV wl = ldv(A.wl_f, i), wr = ldv(A.wr_f, i), wo = ldv(A.wo_f, i), won = ldv(A.wo_f, (i + 4) & (A.n4 - 1));
+    const auto t0 = weak(add(add(wo, wl), ldv(A.qcoef_f, i)));
+    const auto t0sq = mulv(t0, t0);
+    const auto t1 = weak(sub(mulv(t0sq, t0), wr));
+    const auto t2 = mul(weak(sub(mulv(mulv(wr, wr), t0), won)), cst(A.alpha_m261));
+    const auto sum = weak(add(t1, t2));
+    stv(A.q, i, add(mul(mul(sum, ldv(A.qsel_f, i)), cst(A.abase_fix_m261)), ldv(A.q, i)));
+}
+
 // bool_widget.cpp:62-100: q[i] += c_l q_bl (w_l^2 - w_l) + c_r q_br (w_r^2 - w_r) + c_o q_bo (w_o^2 - w_o), wires at index 2i
 __global__ void __launch_bounds__(PT) k_quotient_bool(QuotBoolArgs A)
 {
@@ -866,11 +881,11 @@ int evaluate(const uint64_t* d_coeffs, size_t n, const host::Fr& z, host::Fr* ou
     return BBGPU_OK;
 }
 
-// up to 8 evaluations (each at z[0] or z[1]) in one pair of launches; results land in the jobs' 32-byte device slots
+// up to 10 evaluations (each at z[0] or z[1]) in one pair of launches; results land in the jobs' 32-byte device slots
 int evaluate_batch_to_device(const EvalJob* jobs, int count, const host::Fr z[2], Scratch& S, hipStream_t st)
 {
-    if (count < 1 || count > 8) return BBGPU_ERR_ARG;
-    int rc = S.ensure((size_t)8 * 256 * 32 + 64);
+    if (count < 1 || count > 10) return BBGPU_ERR_ARG;
+    int rc = S.ensure((size_t)10 * 256 * 32 + 64);
     if (rc) return rc;
     EvalBatchArgs A{};
     A.T[0] = make_powtab(z[0]);
@@ -975,6 +990,15 @@ int quotient_mid(QuotMidArgs A, const host::Fr& alpha, const host::Fr& alpha_bas
     A.abase_fix2_m261 = host::limbs_m261(host::fr_mul(alpha_base, f2));
     A.abase_fix3_m261 = host::limbs_m261(host::fr_mul(alpha_base, f3));
     k_quotient_mid<<<pw_blocks(A.n2), PT, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
+    return BBGPU_OK;
+}
+
+int quotient_mimc(QuotMimcArgs A, const host::Fr& alpha_base, const host::Fr& alpha_step, hipStream_t st)
+{
+    A.alpha_m261 = host::limbs_m261(alpha_step);
+    A.abase_fix_m261 = host::limbs_m261(host::fr_mul(alpha_base, host::fr_from_u64(32)));
+    k_quotient_mimc<<<pw_blocks(A.n4), PT, 0, st>>>(A);
     HIPCHK(hipGetLastError());
     return BBGPU_OK;
 }

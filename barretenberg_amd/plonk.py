@@ -18,6 +18,8 @@ LEFT, RIGHT, OUTPUT = 0, 1 << 30, 1 << 31  # ComposerBase::WireType, composer_ba
 PROOF_POINTS = ["W_L", "W_R", "W_O", "Z_1", "T_LO", "T_MID", "T_HI", "PI_Z", "PI_Z_OMEGA"]
 VK_POINTS = ["SIGMA_1", "SIGMA_2", "SIGMA_3", "Q_M", "Q_L", "Q_R", "Q_O", "Q_C"]
 VK_POINTS_BOOL = VK_POINTS + ["Q_BL", "Q_BR", "Q_BO"]
+VK_POINTS_MIMC = VK_POINTS + ["Q_MIMC_COEFFICIENT", "Q_MIMC_SELECTOR"]
+PROOF_EVALS_WIDGET = ["w_l_shifted_eval", "w_r_shifted_eval", "w_o_shifted_eval", "q_c_eval", "q_mimc_coefficient_eval"]  # waffle_types.hpp:39-43
 PROOF_EVALS = ["w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval"]
 
 
@@ -150,6 +152,111 @@ class BoolComposer(StandardComposer):
         }
 
 
+class MiMCComposer(StandardComposer):
+    """waffle::MiMCComposer (composer/mimc_composer.hpp, mimc_composer.cpp:13-250): a MiMC round x_out = (x_in + k + c)^7 is ONE gate
+    (w_l = k, w_r = (x_in + k + c)^3, w_o = x_in) whose result is the NEXT gate's output wire; gates that break the chain get a no-op
+    gate in between to carry the pending output"""
+
+    def __init__(self):
+        super().__init__()
+        self.q_mimc_coefficient, self.q_mimc_selector = [], []
+        self.add_variable(0)
+        self.zero_idx = 0
+        self.current_output_wire = NO_WITNESS
+
+    def _gate(self, a, b, c, q_m, q_l, q_r, q_o, q_c):  # every standard gate: mimc_composer.cpp:13-63
+        if self.current_output_wire != NO_WITNESS:
+            self.create_noop_gate()
+        super()._gate(a, b, c, q_m, q_l, q_r, q_o, q_c)
+        self.q_mimc_coefficient.append(0)
+        self.q_mimc_selector.append(0)
+        self.current_output_wire = NO_WITNESS
+
+    def _zero_selectors(self, coefficient, selector):
+        for q in (self.q_m, self.q_l, self.q_r, self.q_o, self.q_c):
+            q.append(0)
+        self.q_mimc_coefficient.append(coefficient % FR_MODULUS)
+        self.q_mimc_selector.append(selector)
+
+    # mimc_composer.cpp:65-90
+    def create_mimc_gate(self, x_in_idx, x_cubed_idx, k_idx, x_out_idx, mimc_constant):
+        if self.current_output_wire != NO_WITNESS and x_in_idx != self.current_output_wire:
+            self.create_noop_gate()
+        self.w_o.append(x_in_idx); self.w_l.append(k_idx); self.w_r.append(x_cubed_idx)
+        self.current_output_wire = x_out_idx
+        self._zero_selectors(mimc_constant, 1)
+        self.wire_epicycles[k_idx].append((self.n, LEFT))
+        self.wire_epicycles[x_cubed_idx].append((self.n, RIGHT))
+        self.wire_epicycles[x_in_idx].append((self.n, OUTPUT))
+        self.n += 1
+
+    # mimc_composer.cpp:92-120
+    def create_noop_gate(self):
+        self._zero_selectors(0, 0)
+        self.w_l.append(self.zero_idx); self.w_r.append(self.zero_idx)
+        if self.current_output_wire != NO_WITNESS:
+            self.w_o.append(self.current_output_wire)
+            self.wire_epicycles[self.current_output_wire].append((self.n, OUTPUT))
+            self.current_output_wire = NO_WITNESS
+        else:
+            self.w_o.append(self.zero_idx)
+            self.wire_epicycles[self.zero_idx].append((self.n, OUTPUT))
+        self.wire_epicycles[self.zero_idx].append((self.n, LEFT))
+        self.wire_epicycles[self.zero_idx].append((self.n, RIGHT))
+        self.n += 1
+
+    # mimc_composer.cpp:170-250
+    def preprocess(self):
+        if self.current_output_wire != NO_WITNESS:  # close the chain: only the output wire of this gate is constrained
+            self.w_o.append(self.current_output_wire); self.w_l.append(self.zero_idx); self.w_r.append(self.zero_idx)
+            self._zero_selectors(0, 0)
+            self.wire_epicycles[self.current_output_wire].append((self.n, OUTPUT))
+            self.n += 1
+            self.current_output_wire = NO_WITNESS
+        n = self.n
+        log2_n = n.bit_length() - 1
+        if (1 << log2_n) != n:
+            log2_n += 1
+        new_n = 1 << log2_n
+        pad = new_n - n
+        cols = [c + [self.zero_idx] * pad for c in (self.w_l, self.w_r, self.w_o)]
+        sel = [q + [0] * pad for q in (self.q_m, self.q_l, self.q_r, self.q_o, self.q_c, self.q_mimc_selector, self.q_mimc_coefficient)]
+        sigma = [np.arange(new_n, dtype=np.uint32) + np.uint32(t) for t in (LEFT, RIGHT, OUTPUT)]
+        for cyc in self.wire_epicycles:
+            for j, (gate, wire) in enumerate(cyc):
+                nxt_gate, nxt_wire = cyc[0] if j == len(cyc) - 1 else cyc[j + 1]
+                sigma[wire >> 30][gate] = np.uint32((nxt_gate + nxt_wire) & 0xFFFFFFFF)
+        v = self.variables
+        return {
+            "n": new_n,
+            "w_l": to_montgomery_limbs([v[i] for i in cols[0]]), "w_r": to_montgomery_limbs([v[i] for i in cols[1]]),
+            "w_o": to_montgomery_limbs([v[i] for i in cols[2]]),
+            "sigma_1_mapping": sigma[0], "sigma_2_mapping": sigma[1], "sigma_3_mapping": sigma[2],
+            "q_m": to_montgomery_limbs(sel[0]), "q_l": to_montgomery_limbs(sel[1]), "q_r": to_montgomery_limbs(sel[2]),
+            "q_o": to_montgomery_limbs(sel[3]), "q_c": to_montgomery_limbs(sel[4]),
+            "q_mimc_selector": to_montgomery_limbs(sel[5]), "q_mimc_coefficient": to_montgomery_limbs(sel[6]),
+        }
+
+
+def mimc_circuit(num_gates, x0, k):
+    """the MiMCComposer fixture circuit of oracle/plonk_driver.cpp (BB_CIRCUIT=mimc): num_gates - 2 rounds x <- (x + k + c_i)^7, then x + x0"""
+    composer = MiMCComposer()
+    k_idx = composer.add_variable(k)
+    x, x_idx = x0 % FR_MODULUS, composer.add_variable(x0)
+    x0_idx = x_idx
+    for i in range(max(0, num_gates - 2)):
+        c = (0x1000 + 7 * i) + ((i * i + 3) << 64) + (5 << 128)
+        t0 = (x + k + c) % FR_MODULUS
+        cubed = pow(t0, 3, FR_MODULUS)
+        out = cubed * cubed * t0 % FR_MODULUS
+        cubed_idx, out_idx = composer.add_variable(cubed), composer.add_variable(out)
+        composer.create_mimc_gate(x_idx, cubed_idx, k_idx, out_idx, c)
+        x, x_idx = out, out_idx
+    s_idx = composer.add_variable(x + composer.get_variable(x0_idx))
+    composer.create_add_gate(x_idx, x0_idx, s_idx, 1, 1, -1, 0)
+    return composer
+
+
 def bool_circuit(num_gates):
     """the BoolComposer fixture circuit of oracle/plonk_driver.cpp (BB_CIRCUIT=bool): num_gates / 2 pairs of bits a, b constrained
     boolean, c = a b (mul gate), d = a + c (add gate)"""
@@ -236,7 +343,8 @@ def bench_circuit(num_gates, a0, b0):
 
 class _Circuit(C.Structure):
     _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in ("w_l", "w_r", "w_o", "sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping",
-                                                               "q_m", "q_l", "q_r", "q_o", "q_c", "q_bl", "q_br", "q_bo")]
+                                                               "q_m", "q_l", "q_r", "q_o", "q_c", "q_bl", "q_br", "q_bo",
+                                                               "q_mimc_selector", "q_mimc_coefficient")]
 
 
 class Prover:
@@ -265,8 +373,8 @@ class Prover:
         self.gpu._chk(self.gpu.lib.bbgpu_plonk_prover_set_witness(self.handle, *[a.ctypes.data for a in arrs]))
 
     def construct_proof(self):
-        """-> (100,) uint64: nine affine commitments then seven evaluations (waffle_types.hpp:18-45)"""
-        out = np.zeros(100, dtype=np.uint64)
+        """-> (120,) uint64: nine affine commitments, seven evaluations, five widget-dependent evaluations (waffle_types.hpp:18-45)"""
+        out = np.zeros(120, dtype=np.uint64)
         self.gpu._chk(self.gpu.lib.bbgpu_plonk_construct_proof(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out
 
@@ -275,7 +383,8 @@ class Prover:
         out = np.zeros(88, dtype=np.uint64)
         self.gpu.lib.bbgpu_plonk_preprocess.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
         self.gpu._chk(self.gpu.lib.bbgpu_plonk_preprocess(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))))
-        return {k: out[8 * i:8 * i + 8] for i, k in enumerate(VK_POINTS_BOOL if "q_bl" in self._keep else VK_POINTS)}
+        names = VK_POINTS_BOOL if "q_bl" in self._keep else VK_POINTS_MIMC if "q_mimc_selector" in self._keep else VK_POINTS
+        return {k: out[8 * i:8 * i + 8] for i, k in enumerate(names)}
 
     def challenges(self):
         out = np.zeros(20, dtype=np.uint64)
@@ -297,22 +406,26 @@ def hex4(limbs):
     return "%016x%016x%016x%016x" % (int(limbs[3]), int(limbs[2]), int(limbs[1]), int(limbs[0]))
 
 
-def proof_lines(n, proof):
-    """the text form oracle/plonk_driver.cpp prints and tests/golden/plonk_proofs.json stores"""
+def proof_lines(n, proof, mimc=False):
+    """the text form oracle/plonk_driver.cpp prints and tests/golden/plonk_proofs.json stores (with the MiMC widget: two more evaluations)"""
     out = ["n %d" % n]
     for i, name in enumerate(PROOF_POINTS):
         out.append("%s.x %s" % (name, hex4(proof[8 * i:8 * i + 4])))
         out.append("%s.y %s" % (name, hex4(proof[8 * i + 4:8 * i + 8])))
     for i, name in enumerate(PROOF_EVALS):
         out.append("%s %s" % (name, hex4(proof[72 + 4 * i:76 + 4 * i])))
+    if mimc:
+        for name in ("w_o_shifted_eval", "q_mimc_coefficient_eval"):
+            i = PROOF_EVALS_WIDGET.index(name)
+            out.append("%s %s" % (name, hex4(proof[100 + 4 * i:104 + 4 * i])))
     return out
 
 
 def proof_from_lines(lines):
-    """inverse of proof_lines: -> (n, (100,) uint64)"""
+    """inverse of proof_lines (standard part): -> (n, (120,) uint64)"""
     n = int(lines[0].split()[1])
     words = []
     for ln in lines[1:1 + 18 + 7]:
         h = ln.split()[1]
         words += [int(h[16 * (3 - k):16 * (4 - k)], 16) for k in range(4)]
-    return n, np.array(words, dtype=np.uint64)
+    return n, np.array(words + [0] * 20, dtype=np.uint64)

@@ -175,11 +175,17 @@ typedef struct {
     /* optional second widget, all three or none (NULL): the boolean-constraint selectors BoolComposer::preprocess() hands
      * ProverBoolWidget (bool_composer.cpp:68-143, widgets/bool_widget.hpp): q_bl, q_br, q_bo, n x 4 limbs each */
     const uint64_t *q_bl, *q_br, *q_bo;
+    /* or (not both) the MiMC widget's selectors as MiMCComposer::preprocess() hands ProverMiMCWidget (mimc_composer.cpp:170-250,
+     * widgets/mimc_widget.hpp): q_mimc_selector, q_mimc_coefficient (the round constants), n x 4 limbs each; NULL without it.
+     * The proof then also carries w_o_shifted_eval and q_mimc_coefficient_eval. */
+    const uint64_t *q_mimc_selector, *q_mimc_coefficient;
 } bbgpu_plonk_circuit;
-/* proof = waffle::plonk_proof (waffle_types.hpp:18-45) as filled for this circuit: W_L, W_R, W_O, Z_1, T_LO, T_MID, T_HI,
+/* proof = waffle::plonk_proof (waffle_types.hpp:18-45) in its own field order: W_L, W_R, W_O, Z_1, T_LO, T_MID, T_HI,
  * PI_Z, PI_Z_OMEGA (affine x, y: 8 limbs each), then w_l_eval, w_r_eval, w_o_eval, sigma_1_eval, sigma_2_eval,
- * z_1_shifted_eval, linear_eval (4 limbs each); Montgomery form, canonical -- byte-identical to the reference's proof */
-#define BBGPU_PLONK_PROOF_WORDS 100
+ * z_1_shifted_eval, linear_eval, and the widget-dependent w_l_shifted_eval, w_r_shifted_eval, w_o_shifted_eval, q_c_eval,
+ * q_mimc_coefficient_eval (4 limbs each; zero unless a widget fills them: the MiMC widget sets w_o_shifted_eval and
+ * q_mimc_coefficient_eval); Montgomery form, canonical -- byte-identical to the reference's proof */
+#define BBGPU_PLONK_PROOF_WORDS 120
 int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* circuit, int srs_handle); /* returns a prover handle >= 0 */
 int bbgpu_plonk_prover_set_witness(int prover, const uint64_t* w_l, const uint64_t* w_r, const uint64_t* w_o);
 int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF_WORDS]); /* Prover::construct_proof, prover.cpp:661-670 */

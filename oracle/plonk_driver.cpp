@@ -19,6 +19,8 @@
 //                                              resident prover (bbgpu_plonk_*), so that it proves the very same circuit
 //   BB_CIRCUIT=bool in the environment switches every mode to a BoolComposer circuit (arithmetic + bool widget): <num_gates> / 2 pairs of
 //   bits a_i, b_i constrained boolean, c_i = a_i b_i (mul gate), d_i = a_i + c_i (add gate)
+//   BB_CIRCUIT=mimc: a MiMCComposer circuit (arithmetic + MiMC widget): a chain of <num_gates> - 2 MiMC rounds x <- (x + k + c_i)^7 from fixed
+//   witnesses, then an addition gate on the result; the proof then carries w_o_shifted_eval and q_mimc_coefficient_eval as well
 //   plonk_xxx verify <num_gates> < proof       rebuild the same circuit's Verifier and check a proof given in the `prove` text
 //                                              format on stdin (used to verify proofs made by the native GPU prover)
 #include <barretenberg/curves/bn254/fq.hpp>
@@ -26,12 +28,14 @@
 #include <barretenberg/curves/bn254/g1.hpp>
 #include <barretenberg/curves/bn254/g2.hpp>
 #include <barretenberg/waffle/composer/bool_composer.hpp>
+#include <barretenberg/waffle/composer/mimc_composer.hpp>
 #include <barretenberg/waffle/composer/standard_composer.hpp>
 #include <barretenberg/waffle/proof_system/preprocess.hpp>
 #include <barretenberg/waffle/proof_system/prover/prover.hpp>
 #include <barretenberg/waffle/proof_system/verifier/verifier.hpp>
 #include <barretenberg/waffle/proof_system/widgets/arithmetic_widget.hpp>
 #include <barretenberg/waffle/proof_system/widgets/bool_widget.hpp>
+#include <barretenberg/waffle/proof_system/widgets/mimc_widget.hpp>
 #include <barretenberg/waffle/stdlib/field/field.hpp>
 
 #include <arpa/inet.h>
@@ -122,7 +126,10 @@ int prove(size_t num_gates, bool trace)
     const char* en[12] = { "w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval", "w_l_shifted_eval",
                            "w_r_shifted_eval", "w_o_shifted_eval", "q_c_eval", "q_mimc_coefficient_eval" };
     for (int i = 0; i < 7; i++) hex4(en[i], ev[i]->data); // the standard arithmetic circuit fills these; the rest stay unset
-    (void)en; (void)ev;
+    if (prover.widgets.size() > 1 && dynamic_cast<const waffle::ProverMiMCWidget*>(prover.widgets[1].get())) {
+        hex4(en[9], ev[9]->data);   // w_o_shifted_eval (prover.cpp:499-502)
+        hex4(en[11], ev[11]->data); // q_mimc_coefficient_eval (mimc_widget.cpp:92-95)
+    }
     if (trace) {
         hex4("beta", prover.challenges.beta.data);
         hex4("gamma", prover.challenges.gamma.data);
@@ -165,9 +172,35 @@ void build_bool_circuit(waffle::BoolComposer& composer, size_t num_gates)
         composer.create_add_gate({ a, c, d, one, one, minus_one, zero });
     }
 }
+// MiMCComposer circuit (mimc_composer.cpp): rounds x_out = (x_in + k + c)^7 as one gate each (w_l = k, w_r = (x_in + k + c)^3, w_o = x_in, next w_o = x_out)
+void build_mimc_circuit(waffle::MiMCComposer& composer, size_t num_gates)
+{
+    fr::field_t x = fr::to_montgomery_form({ { 0x1111111122222222ULL, 0x3333333344444444ULL, 0x5555555566666666ULL, 0x0777777788888888ULL } });
+    const fr::field_t k = fr::to_montgomery_form({ { 0x9999aaaabbbbccccULL, 0xddddeeeeffff0000ULL, 0x1234123412341234ULL, 0x0abcdefabcdefabcULL } });
+    const uint32_t k_idx = composer.add_variable(k);
+    uint32_t x_idx = composer.add_variable(x);
+    const uint32_t x0_idx = x_idx;
+    for (size_t i = 0; i + 2 < num_gates; ++i) {
+        const fr::field_t c = fr::to_montgomery_form({ { 0x1000 + 7 * i, i * i + 3, 5, 0 } });
+        const fr::field_t t0 = fr::add(fr::add(x, k), c);
+        const fr::field_t cubed = fr::mul(fr::sqr(t0), t0);
+        const fr::field_t out = fr::mul(fr::sqr(cubed), t0);
+        const uint32_t cubed_idx = composer.add_variable(cubed), out_idx = composer.add_variable(out);
+        composer.create_mimc_gate({ x_idx, cubed_idx, k_idx, out_idx, c });
+        x = out;
+        x_idx = out_idx;
+    }
+    const uint32_t sum_idx = composer.add_variable(fr::add(x, composer.get_variable(x0_idx)));
+    composer.create_add_gate({ x_idx, x0_idx, sum_idx, fr::one, fr::one, fr::neg_one(), fr::zero });
+}
 std::unique_ptr<waffle::ComposerBase> make_circuit(size_t num_gates)
 {
     const char* kind = getenv("BB_CIRCUIT");
+    if (kind && !strcmp(kind, "mimc")) {
+        auto c = std::make_unique<waffle::MiMCComposer>(num_gates);
+        build_mimc_circuit(*c, num_gates);
+        return c;
+    }
     if (kind && !strcmp(kind, "bool")) {
         auto c = std::make_unique<waffle::BoolComposer>(num_gates);
         build_bool_circuit(*c, num_gates);
@@ -186,7 +219,8 @@ int dump(size_t num_gates, const char* path)
     waffle::Prover prover = composer->preprocess();
     const waffle::ProverArithmeticWidget* w = dynamic_cast<const waffle::ProverArithmeticWidget*>(prover.widgets[0].get());
     const waffle::ProverBoolWidget* wb = prover.widgets.size() > 1 ? dynamic_cast<const waffle::ProverBoolWidget*>(prover.widgets[1].get()) : nullptr;
-    if (!w || prover.widgets.size() > 2 || (prover.widgets.size() == 2 && !wb)) return 3;
+    const waffle::ProverMiMCWidget* wm = prover.widgets.size() > 1 ? dynamic_cast<const waffle::ProverMiMCWidget*>(prover.widgets[1].get()) : nullptr;
+    if (!w || prover.widgets.size() > 2 || (prover.widgets.size() == 2 && !wb && !wm)) return 3;
     FILE* f = fopen(path, "wb");
     if (!f) return 1;
     const uint64_t n = prover.n;
@@ -201,6 +235,10 @@ int dump(size_t num_gates, const char* path)
     if (wb) { // bool widget selectors follow (bool_widget.hpp)
         const barretenberg::polynomial* bsel[3] = { &wb->q_bl, &wb->q_br, &wb->q_bo };
         for (auto* p : bsel) wr(f, const_cast<barretenberg::polynomial*>(p)->get_coefficients(), n * 32);
+    }
+    if (wm) { // MiMC widget selectors follow (mimc_widget.hpp): selector, then round constants
+        const barretenberg::polynomial* msel[2] = { &wm->q_mimc_selector, &wm->q_mimc_coefficient };
+        for (auto* p : msel) wr(f, const_cast<barretenberg::polynomial*>(p)->get_coefficients(), n * 32);
     }
     fclose(f);
     printf("n %zu\n", (size_t)n);
@@ -226,7 +264,14 @@ int vk(size_t num_gates)
         snprintf(nm, sizeof nm, "%s.x", qn[i]); hex4(nm, inst[i].x.data);
         snprintf(nm, sizeof nm, "%s.y", qn[i]); hex4(nm, inst[i].y.data);
     }
-    if (verifier.verifier_widgets.size() > 1) { // bool widget: commitments to q_bl, q_br, q_bo (bool_widget.cpp:118-152)
+    if (verifier.verifier_widgets.size() > 1 && verifier.verifier_widgets[1]->instance.size() == 2) { // MiMC widget (mimc_widget.cpp:133-160)
+        const char* mn[2] = { "Q_MIMC_COEFFICIENT", "Q_MIMC_SELECTOR" };
+        const auto& minst = verifier.verifier_widgets[1]->instance;
+        for (int i = 0; i < 2; i++) {
+            snprintf(nm, sizeof nm, "%s.x", mn[i]); hex4(nm, minst[i].x.data);
+            snprintf(nm, sizeof nm, "%s.y", mn[i]); hex4(nm, minst[i].y.data);
+        }
+    } else if (verifier.verifier_widgets.size() > 1) { // bool widget: commitments to q_bl, q_br, q_bo (bool_widget.cpp:118-152)
         const char* bn[3] = { "Q_BL", "Q_BR", "Q_BO" };
         const auto& binst = verifier.verifier_widgets[1]->instance;
         for (int i = 0; i < 3; i++) {
@@ -268,6 +313,9 @@ int verify(size_t num_gates)
     fr::field_t* ev[7] = { &proof.w_l_eval, &proof.w_r_eval, &proof.w_o_eval, &proof.sigma_1_eval, &proof.sigma_2_eval, &proof.z_1_shifted_eval, &proof.linear_eval };
     const char* en[7] = { "w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval" };
     for (int i = 0; i < 7; i++) if (!rd4(en[i], ev[i]->data)) return 4;
+    if (prover.widgets.size() > 1 && dynamic_cast<const waffle::ProverMiMCWidget*>(prover.widgets[1].get())) {
+        if (!rd4("w_o_shifted_eval", proof.w_o_shifted_eval.data) || !rd4("q_mimc_coefficient_eval", proof.q_mimc_coefficient_eval.data)) return 4;
+    }
     bool ok = verifier.verify_proof(proof);
     printf("verified %d\n", ok ? 1 : 0);
     return ok ? 0 : 2;

@@ -299,3 +299,42 @@ def test_resident_prover_with_bool_widget(gpu, srs65536, golden, gates):
             assert r.returncode == 0 and r.stdout.strip() == "verified 1", (r.stdout, r.stderr[-500:])
     finally:
         prover.destroy()
+
+
+MIMC_X0 = 0x0777777788888888555555556666666633333333444444441111111122222222
+MIMC_K = 0x0ABCDEFABCDEFABC1234123412341234DDDDEEEEFFFF00009999AAAABBBBCCCC
+
+
+@pytest.mark.parametrize("gates", [3, 6, 30, 93, 4094])
+def test_resident_prover_with_mimc_widget(gpu, srs65536, golden, gates):
+    """third widget: a MiMCComposer circuit (arithmetic + MiMC widget, mimc_widget.cpp) -- a chain of x <- (x + k + c_i)^7 rounds, whose
+    identity reads w_o at the NEXT row, so the proof carries w_o(z*omega) and q_mimc_coefficient(z) as well.  Proof bytes (28 lines), all five
+    challenges and the verification key (10 commitments) equal the reference's; its Verifier accepts the proof."""
+    from barretenberg_amd.plonk import VK_POINTS_MIMC, Prover, hex4, mimc_circuit, proof_lines
+    from oracle.pyoracle import Oracle
+    fx = golden("plonk_trace.json")["mimc"]
+    state = mimc_circuit(gates, MIMC_X0, MIMC_K).preprocess()
+    prover = Prover(gpu, state, srs65536)
+    try:
+        proof = prover.construct_proof()
+        got = proof_lines(state["n"], proof, mimc=True)
+        ch = prover.challenges()
+        for name in ("gamma", "beta", "alpha", "z", "nu"):
+            assert hx(ch[name])[0] == fx["challenges"][str(gates)][name], name
+        assert got == fx["proofs"][str(gates)][:28]
+        vk = prover.preprocess()
+        ref = {ln.split()[0]: ln.split()[1] for ln in fx["verification_keys"][str(gates)][1:]}
+        for k in VK_POINTS_MIMC:
+            if int(vk[k][7]) >> 63:  # commitment to a zero selector: see the arithmetic-widget test
+                rp = np.array([int(ref[k + c][16 * (3 - j):16 * (4 - j)], 16) for c in (".x", ".y") for j in range(4)], dtype=np.uint64)
+                assert not Oracle().g1_on_curve(rp), k
+                continue
+            assert hex4(vk[k][0:4]) == ref[k + ".x"] and hex4(vk[k][4:8]) == ref[k + ".y"], k
+        assert np.array_equal(prover.construct_proof(), proof)
+        exe = os.path.join(ROOT, "oracle", "_ref", "plonk_cpu")
+        if os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "transcript.dat")):
+            r = subprocess.run([exe, "verify", str(gates)], input="\n".join(got) + "\n", cwd=ROOT, capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, OMP_NUM_THREADS="16", BB_CIRCUIT="mimc"))
+            assert r.returncode == 0 and r.stdout.strip() == "verified 1", (r.stdout, r.stderr[-500:])
+    finally:
+        prover.destroy()

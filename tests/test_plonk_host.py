@@ -71,3 +71,33 @@ def test_bool_composer_mirror_digests(trace, gates):
     for k, d in want.items():
         if k != "n":
             assert hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() == d, k
+
+
+MIMC_X0 = 0x0777777788888888555555556666666633333333444444441111111122222222
+MIMC_K = 0x0ABCDEFABCDEFABC1234123412341234DDDDEEEEFFFF00009999AAAABBBBCCCC
+
+
+@pytest.mark.parametrize("gates", [3, 6, 30, 93, 4094])
+def test_mimc_composer_mirror_digests(trace, gates):
+    """MiMCComposer mirror (mimc_composer.cpp:13-250: chained MiMC gates, the no-op gates that carry a pending output wire, the closing
+    gate) vs the reference composer's Prover state, SHA-256 of all thirteen arrays"""
+    from barretenberg_amd.plonk import mimc_circuit
+    st = mimc_circuit(gates, MIMC_X0, MIMC_K).preprocess()
+    want = trace["mimc"]["input_digests"][str(gates)]
+    assert st["n"] == want["n"]
+    for k, d in want.items():
+        if k != "n":
+            assert hashlib.sha256(np.ascontiguousarray(st[k]).tobytes()).hexdigest() == d, k
+
+
+def test_mimc_composer_noop_and_closing_gates():
+    """a MiMC gate whose input is not the pending output wire gets a no-op gate in front of it, and a chain left open at preprocess() is
+    closed by a gate constraining only w_o (mimc_composer.cpp:65-120, 172-190)"""
+    from barretenberg_amd.plonk import MiMCComposer
+    c = MiMCComposer()
+    k, a, a3, a7, b, b3, b7 = (c.add_variable(v) for v in (5, 11, 12, 13, 21, 22, 23))
+    c.create_mimc_gate(a, a3, k, a7, 9)
+    c.create_mimc_gate(b, b3, k, b7, 10)  # b is not a7: no-op gate carrying a7 goes in between
+    assert c.n == 3 and c.w_o == [a, a7, b] and c.q_mimc_selector == [1, 0, 1]
+    st = c.preprocess()  # closing gate for b7
+    assert st["n"] == 4 and c.w_o[3] == b7 and c.w_l[3] == c.zero_idx

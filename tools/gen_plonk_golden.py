@@ -91,6 +91,29 @@ def main():
             dig[k] = hashlib.sha256(b[o:o + 32 * n]).hexdigest(); o += 32 * n
         out["bool"]["input_digests"][str(gates)] = dig
         os.remove(path)
+    # MiMCComposer circuit (arithmetic + MiMC widget; `BB_CIRCUIT=mimc plonk_cpu ...`): a chain of MiMC rounds, then one addition gate
+    menv = dict(os.environ, BB_CIRCUIT="mimc")
+    msel = SELECTORS + ("q_mimc_selector", "q_mimc_coefficient")
+    out["mimc"] = {"proofs": {}, "challenges": {}, "verification_keys": {}, "input_digests": {}}
+    for gates in (3, 6, 30, 93, 4094):  # n = 4, 8, 32, 128 (91 rounds + noop + add gate pad to 128), 4096
+        lines = subprocess.run([EXE, "trace", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True, env=menv).stdout.strip().split("\n")
+        out["mimc"]["challenges"][str(gates)] = {ln.split()[0]: ln.split()[1] for ln in lines if ln.split()[0] in ("beta", "gamma", "alpha", "z", "nu")}
+        out["mimc"]["proofs"][str(gates)] = [ln for ln in lines if ln.split()[0] not in ("beta", "gamma", "alpha", "z", "nu")]
+        out["mimc"]["verification_keys"][str(gates)] = subprocess.run([EXE, "vk", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True,
+                                                                      env=menv).stdout.strip().split("\n")
+        path = "/tmp/plonk_dump_mimc_%d.bin" % gates
+        subprocess.run([EXE, "dump", str(gates), path], cwd=ROOT, check=True, stdout=subprocess.DEVNULL, env=menv)
+        b = open(path, "rb").read()
+        n = int.from_bytes(b[8:16], "little")
+        o, dig = 16, {"n": n}
+        for k in FIELDS64:
+            dig[k] = hashlib.sha256(b[o:o + 32 * n]).hexdigest(); o += 32 * n
+        for k in MAPS:
+            dig[k] = hashlib.sha256(b[o:o + 4 * n]).hexdigest(); o += 4 * n
+        for k in msel:
+            dig[k] = hashlib.sha256(b[o:o + 32 * n]).hexdigest(); o += 32 * n
+        out["mimc"]["input_digests"][str(gates)] = dig
+        os.remove(path)
     if not big:  # keep the large-circuit entries of an earlier run
         old = json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_trace.json")))
         for key in ("challenges", "input_digests", "verification_keys"):
