@@ -314,7 +314,12 @@ def main():
                                          "note": "two MSMs in flight: stages of consecutive steps overlap, so they sum to more than ms_per_step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "msm_accumulate_kernel", "kernel_ms": acc_ms, "kernel_ms_alone": float(stage[3]),
-                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes},
+                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes,
+                         # the bound that does apply: one mixed XYZZ addition per (point, window) = 1,467 v_mad_u64_u32 per lane,
+                         # against the chip's measured issue rate for that instruction (470 G wave-instructions/s)
+                         "valu": {"bound": "v_mad_u64_u32 issue", "achieved": n * (we - wb) * 1467 / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0,
+                                  "peak": 470e9 * 64 / 1e12, "unit": "T lane-mad/s",
+                                  "frac": (n * (we - wb) * 1467 / (acc_ms * 1e-3)) / (470e9 * 64) if acc_ms > 0 else 0.0}},
             "ntt": {"metric": "Fr radix-2 NTT elements/s at n=2^%d, in place on a device-resident vector" % args.log2n,
                     "fft": ntt["fft"], "coset_fft": ntt["coset_fft"],
                     "roofline": {"bound": "hbm", "achieved": ntt_bytes / (ntt["fft"]["device_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
