@@ -97,6 +97,9 @@ class PlonkProver {
     uint64_t* qm_lagrange[2] = {};
     uint64_t* qm_coeff[2] = {};
     uint64_t* qm_fft4n[2] = {};
+    // optional sequential widget (sequential_widget.hpp): q_o_next
+    bool has_seq = false;
+    uint64_t *qs_lagrange = nullptr, *qs_coeff = nullptr, *qs_fft2n = nullptr;
     // per proof
     uint64_t* w[3] = {};        // wire polynomials, coefficient form          (Prover::w_l, w_r, w_o after :130-132)
     uint64_t* sigma[3] = {};    // beta * sigma_i, coefficient form             (after :245-247)
@@ -198,6 +201,13 @@ class PlonkProver {
                 qm_fft4n[k] = qm_fft4n[0] + (size_t)k * 4 * n * 4;
                 HIPCHK(hipMemcpy(qm_lagrange[k], hmm[k], fb, hipMemcpyHostToDevice));
             }
+        }
+        has_seq = c->q_o_next != nullptr;
+        if (has_seq) {
+            RC(dalloc(&qs_lagrange, fb));
+            RC(dalloc(&qs_coeff, fb));
+            RC(dalloc(&qs_fft2n, 2 * fb));
+            HIPCHK(hipMemcpy(qs_lagrange, c->q_o_next, fb, hipMemcpyHostToDevice));
         }
         RC(dalloc(&roots, fb));
         RC(dalloc(&l_1, 2 * fb));
@@ -308,6 +318,12 @@ class PlonkProver {
             for (int k = 0; k < 3; k++) RC(poly::copy_pad(qb_fft2n[k], qb_coeff[k], n, 2 * n, st));
             RC(ntt_batch(qb_fft2n[0], 2 * n, 3, BBGPU_COSET_FFT));
         }
+        if (has_seq) { // sequential_widget.cpp:49-54 without the alpha scaling (applied in quotient_seq)
+            RC(copy(qs_coeff, qs_lagrange, n));
+            RC(ntt(qs_coeff, n, BBGPU_IFFT));
+            RC(poly::copy_pad(qs_fft2n, qs_coeff, n, 2 * n, st));
+            RC(ntt(qs_fft2n, 2 * n, BBGPU_COSET_FFT));
+        }
         if (has_mimc) { // mimc_widget.cpp:60-67 without the alpha scaling (applied in quotient_mimc)
             RC(copy(qm_coeff[0], qm_lagrange[0], 2 * n));
             RC(ntt_batch(qm_coeff[0], n, 2, BBGPU_IFFT));
@@ -407,6 +423,14 @@ class PlonkProver {
         M.q = (uint32_t*)quotient_mid;
         M.n2 = (uint32_t)n2;
         RC(poly::quotient_mid(M, challenges.alpha, alpha_base, st));
+        if (has_seq) { // sequential_widget.cpp:47-62: old_alpha = (alpha_base * alpha) / alpha = the arithmetic widget's own power; hands alpha_base * alpha on unchanged
+            poly::QuotSeqArgs Sq{};
+            Sq.wo_f = M.wo_f;
+            Sq.qon_f = (const uint32_t*)qs_fft2n;
+            Sq.q = (uint32_t*)quotient_mid;
+            Sq.n2 = (uint32_t)n2;
+            RC(poly::quotient_seq(Sq, alpha_base, st));
+        }
         if (has_bool) { // the widget chain: the arithmetic widget hands on alpha_base * alpha (arithmetic_widget.cpp:103), the bool widget uses it and the next two powers
             const Fr a5 = host::fr_mul(alpha_base, challenges.alpha), a6 = host::fr_mul(a5, challenges.alpha), a7 = host::fr_mul(a6, challenges.alpha);
             poly::QuotBoolArgs Bq{};
@@ -474,16 +498,14 @@ class PlonkProver {
                                       { quotient_large, 3 * n, 0, slots + 6 * 4 },
                                       // MiMC widget: REQUIRES_W_O_SHIFTED (prover.cpp:499-502) and compute_proof_elements (mimc_widget.cpp:92-95)
                                       { w[2], n, 1, slots + 7 * 4 }, { qm_coeff[1], n, 0, slots + 8 * 4 } };
-        const int nev = has_mimc ? 9 : 7;
+        const int nev = has_mimc ? 9 : has_seq ? 8 : 7; // the sequential widget is REQUIRES_W_O_SHIFTED too (sequential_widget.cpp:16)
         RC(poly::evaluate_batch_to_device(ej, nev, zs, scratch, st));
         HIPCHK(hipMemcpyAsync(h_slots, slots, (size_t)nev * 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         Fr ev[9];
         memcpy(ev, h_slots, (size_t)nev * 32);
-        if (has_mimc) {
-            proof.w_o_shifted_eval = ev[7];
-            proof.q_mimc_coefficient_eval = ev[8];
-        }
+        if (has_mimc || has_seq) proof.w_o_shifted_eval = ev[7];
+        if (has_mimc) proof.q_mimc_coefficient_eval = ev[8];
         proof.w_l_eval = ev[0];
         proof.w_r_eval = ev[1];
         proof.w_o_eval = ev[2];
@@ -517,23 +539,28 @@ class PlonkProver {
         const Fr cs[10] = { lt_z1, host::fr_mul(lt_sigma3, beta_inv), host::fr_mul(w_lr, alpha4), host::fr_mul(proof.w_l_eval, alpha4),
                             host::fr_mul(proof.w_r_eval, alpha4), host::fr_mul(proof.w_o_eval, alpha4), alpha4,
                             boolmul(proof.w_l_eval, alpha5), boolmul(proof.w_r_eval, alpha6), boolmul(proof.w_o_eval, alpha7) };
-        int terms = has_bool ? 10 : 7;
-        const uint64_t* psm[8];
-        Fr csm[8];
+        const uint64_t* pl[12];
+        Fr cl[12];
+        int terms = 7;
+        for (int j = 0; j < 7; j++) { pl[j] = ps[j]; cl[j] = cs[j]; }
+        if (has_seq) { // sequential_widget.cpp:64-74: w_o(z omega) * alpha^4 on q_o_next
+            pl[terms] = qs_coeff;
+            cl[terms++] = host::fr_mul(proof.w_o_shifted_eval, alpha4);
+        }
+        if (has_bool)
+            for (int j = 7; j < 10; j++) { pl[terms] = ps[j]; cl[terms++] = cs[j]; }
         if (has_mimc) { // mimc_widget.cpp:97-113 with alpha_base = alpha^5, alpha_step = alpha
             const Fr t0 = host::fr_add(host::fr_add(proof.w_o_eval, proof.w_l_eval), proof.q_mimc_coefficient_eval);
             const Fr a = host::fr_sub(host::fr_mul(host::fr_sqr(t0), t0), proof.w_r_eval);
             const Fr b = host::fr_mul(host::fr_sub(host::fr_mul(host::fr_sqr(proof.w_r_eval), t0), proof.w_o_shifted_eval), alpha);
-            for (int j = 0; j < 7; j++) { psm[j] = ps[j]; csm[j] = cs[j]; }
-            psm[7] = qm_coeff[0];
-            csm[7] = host::fr_mul(host::fr_add(b, a), alpha5);
-            terms = 8;
+            pl[terms] = qm_coeff[0];
+            cl[terms++] = host::fr_mul(host::fr_add(b, a), alpha5);
         }
-        for (int j = 0; j < terms; j++) A.p[j] = (const uint32_t*)(has_mimc ? psm[j] : ps[j]);
+        for (int j = 0; j < terms; j++) A.p[j] = (const uint32_t*)pl[j];
         A.count = terms;
         A.out = (uint32_t*)r;
         A.n = (uint32_t)n;
-        RC(poly::lincomb(A, has_mimc ? csm : cs, st));
+        RC(poly::lincomb(A, cl, st));
         RC(poly::evaluate(r, n, zc, &proof.linear_eval, scratch, st)); // :536
         return BBGPU_OK;
     }
@@ -556,7 +583,7 @@ class PlonkProver {
         const Fr z_pow_n = host::fr_pow(challenges.z, (uint64_t)n), z_pow_2n = host::fr_pow(challenges.z, (uint64_t)2 * n);
         // :567-595 as one linear combination of nine resident vectors
         poly::LinCombArgs A{};
-        // with the MiMC widget: w_o joins the shifted opening at nu^8 (prover.cpp:627-635) and q_mimc_coefficient the main one at nu^9
+        // with the MiMC or the sequential widget: w_o joins the shifted opening at nu^8 (prover.cpp:627-635) and q_mimc_coefficient the main one at nu^9
         // (mimc_widget.cpp:115-123)
         const Fr nu9 = host::fr_mul(nu[7], nu[0]);
         const uint64_t* ps[10] = { quotient_large, quotient_large + n * 4, quotient_large + 2 * n * 4, r, w[0], w[1], w[2], sigma[0], sigma[1], qm_coeff[1] };
@@ -570,7 +597,7 @@ class PlonkProver {
         poly::LinCombArgs B{};
         B.p[0] = (const uint32_t*)z;
         B.p[1] = (const uint32_t*)w[2];
-        B.count = has_mimc ? 2 : 1;
+        B.count = (has_mimc || has_seq) ? 2 : 1;
         B.out = (uint32_t*)tmp[1];
         B.n = (uint32_t)n;
         RC(poly::lincomb(B, &nu[6], st)); // nu^7 Z (+ nu^8 w_o)
@@ -604,9 +631,15 @@ class PlonkProver {
         RC(commit(q3, 3, out + 3));
         const uint64_t* q2[2] = { q_coeff[3], q_coeff[4] };
         RC(commit(q2, 2, out + 6));
+        int at = 8;
+        if (has_seq) { // sequential_widget.cpp:79-106, second widget of the ExtendedComposer's chain
+            const uint64_t* qn[1] = { qs_coeff };
+            RC(commit(qn, 1, out + at));
+            at += 1;
+        }
         if (has_bool) { // bool_widget.cpp:118-152
             const uint64_t* qb[3] = { qb_coeff[0], qb_coeff[1], qb_coeff[2] };
-            RC(commit(qb, 3, out + 8));
+            RC(commit(qb, 3, out + at));
         }
         if (has_mimc) { // mimc_widget.cpp:125-160: q_mimc_coefficient first, then q_mimc_selector
             const uint64_t* qmm[2] = { qm_coeff[1], qm_coeff[0] };
@@ -672,8 +705,8 @@ int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* c, int srs_handle)
         set_error("bool widget selectors: give all of q_bl, q_br, q_bo or none");
         return BBGPU_ERR_ARG;
     }
-    if ((c->q_mimc_selector != nullptr) != (c->q_mimc_coefficient != nullptr) || (c->q_mimc_selector && c->q_bl)) {
-        set_error("MiMC widget selectors: give both q_mimc_selector and q_mimc_coefficient or neither, and not together with the bool widget");
+    if ((c->q_mimc_selector != nullptr) != (c->q_mimc_coefficient != nullptr) || (c->q_mimc_selector && (c->q_bl || c->q_o_next))) {
+        set_error("MiMC widget selectors: give both q_mimc_selector and q_mimc_coefficient or neither, and not together with the bool or the sequential widget");
         return BBGPU_ERR_ARG;
     }
     if (c->n < 4 || (c->n & (c->n - 1)) || c->n > ((size_t)1 << 20)) {

@@ -45,6 +45,13 @@ struct QuotMidArgs {
     uint32_t n2;
     Limbs9 alpha_m256, alpha_fix_m261, alpha2_fix_m261, abase_m261, abase_fix2_m261, abase_fix3_m261;
 };
+struct QuotSeqArgs {
+    const uint32_t* wo_f;   // 4n coset evaluations of w_o (read at index 2i + 4: the next gate's output wire)
+    const uint32_t* qon_f;  // 2n coset evaluations of q_o_next, unscaled
+    uint32_t* q;            // quotient_mid, accumulated into
+    uint32_t n2;
+    Limbs9 c_fix_m261;
+};
 struct QuotBoolArgs {
     const uint32_t *wl_f, *wr_f, *wo_f;    // 4n coset evaluations (read at index 2i)
     const uint32_t *qbl_f, *qbr_f, *qbo_f; // 2n coset evaluations of the bool selectors, unscaled
@@ -60,8 +67,8 @@ struct QuotMimcArgs {
     Limbs9 alpha_m261, abase_fix_m261;  // alpha_step; alpha_base * 2^5
 };
 struct LinCombArgs {
-    const uint32_t* p[10];
-    Limbs9 c[10];
+    const uint32_t* p[12];
+    Limbs9 c[12];
     const uint32_t* out_add; // optional addend (memory form), may be null
     uint32_t* out;
     uint32_t n;
@@ -119,6 +126,7 @@ int quotient_large(QuotLargeArgs A, const host::Fr& root4n, const host::Fr& beta
 int quotient_mid(QuotMidArgs A, const host::Fr& alpha, const host::Fr& alpha_base, hipStream_t st);
 int quotient_mimc(QuotMimcArgs A, const host::Fr& alpha_base, const host::Fr& alpha_step, hipStream_t st);
 int quotient_bool(QuotBoolArgs A, const host::Fr& c_left, const host::Fr& c_right, const host::Fr& c_out, hipStream_t st);
+int quotient_seq(QuotSeqArgs A, const host::Fr& c, hipStream_t st); // sequential_widget.cpp:47-62: quotient_mid[i] += c q_o_next[i] w_o[2i + 4]
 int divide_by_pseudo_vanishing(uint64_t* d_coeffs, int log2n, int log2N, hipStream_t st);
 int lagrange_l1_fft(uint64_t* d_l1, uint64_t* d_tmp, int log2n, int log2N, Scratch& S, hipStream_t st);
 int lincomb(LinCombArgs A, const host::Fr* coeffs, hipStream_t st);

@@ -590,6 +590,16 @@ __global__ void __launch_bounds__(PT) k_quotient_mimc(QuotMimcArgs A)
     stv(A.q, i, add(mul(mul(sum, ldv(A.qsel_f, i)), cst(A.abase_fix_m261)), ldv(A.q, i)));
 }
 
+// sequential_widget.cpp:47-62: q[i] += c q_o_next[i] w_o[2i + 4] on the 2n coset (index 2i + 4 of the 4n evaluations = the next gate's row)
+__global__ void __launch_bounds__(PT) k_quotient_seq(QuotSeqArgs A)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n2) return;
+    const uint32_t m4 = 2 * A.n2 - 1;
+    auto t = mul(mul(ldv(A.qon_f, i), ldv(A.wo_f, (2 * i + 4) & m4)), cst(A.c_fix_m261));
+    stv(A.q, i, add(t, ldv(A.q, i)));
+}
+
 // bool_widget.cpp:62-100: q[i] += c_l q_bl (w_l^2 - w_l) + c_r q_br (w_r^2 - w_r) + c_o q_bo (w_o^2 - w_o), wires at index 2i
 __global__ void __launch_bounds__(PT) k_quotient_bool(QuotBoolArgs A)
 {
@@ -999,6 +1009,14 @@ int quotient_mimc(QuotMimcArgs A, const host::Fr& alpha_base, const host::Fr& al
     A.alpha_m261 = host::limbs_m261(alpha_step);
     A.abase_fix_m261 = host::limbs_m261(host::fr_mul(alpha_base, host::fr_from_u64(32)));
     k_quotient_mimc<<<pw_blocks(A.n4), PT, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
+    return BBGPU_OK;
+}
+
+int quotient_seq(QuotSeqArgs A, const host::Fr& c, hipStream_t st)
+{
+    A.c_fix_m261 = host::limbs_m261(host::fr_mul(c, host::fr_from_u64(32)));
+    k_quotient_seq<<<pw_blocks(A.n2), PT, 0, st>>>(A);
     HIPCHK(hipGetLastError());
     return BBGPU_OK;
 }

@@ -19,6 +19,7 @@ PROOF_POINTS = ["W_L", "W_R", "W_O", "Z_1", "T_LO", "T_MID", "T_HI", "PI_Z", "PI
 VK_POINTS = ["SIGMA_1", "SIGMA_2", "SIGMA_3", "Q_M", "Q_L", "Q_R", "Q_O", "Q_C"]
 VK_POINTS_BOOL = VK_POINTS + ["Q_BL", "Q_BR", "Q_BO"]
 VK_POINTS_MIMC = VK_POINTS + ["Q_MIMC_COEFFICIENT", "Q_MIMC_SELECTOR"]
+VK_POINTS_EXTENDED = VK_POINTS + ["Q_O_NEXT", "Q_BL", "Q_BR", "Q_BO"]  # ExtendedComposer: arithmetic, sequential, bool widgets
 PROOF_EVALS_WIDGET = ["w_l_shifted_eval", "w_r_shifted_eval", "w_o_shifted_eval", "q_c_eval", "q_mimc_coefficient_eval"]  # waffle_types.hpp:39-43
 PROOF_EVALS = ["w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval"]
 
@@ -344,7 +345,7 @@ def bench_circuit(num_gates, a0, b0):
 class _Circuit(C.Structure):
     _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in ("w_l", "w_r", "w_o", "sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping",
                                                                "q_m", "q_l", "q_r", "q_o", "q_c", "q_bl", "q_br", "q_bo",
-                                                               "q_mimc_selector", "q_mimc_coefficient")]
+                                                               "q_mimc_selector", "q_mimc_coefficient", "q_o_next")]
 
 
 class Prover:
@@ -380,10 +381,11 @@ class Prover:
 
     def preprocess(self):
         """waffle::preprocess(prover): -> dict of the eight verification-key commitments, each (8,) uint64 affine"""
-        out = np.zeros(88, dtype=np.uint64)
+        out = np.zeros(96, dtype=np.uint64)
         self.gpu.lib.bbgpu_plonk_preprocess.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
         self.gpu._chk(self.gpu.lib.bbgpu_plonk_preprocess(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))))
-        names = VK_POINTS_BOOL if "q_bl" in self._keep else VK_POINTS_MIMC if "q_mimc_selector" in self._keep else VK_POINTS
+        names = VK_POINTS_EXTENDED if "q_o_next" in self._keep else VK_POINTS_BOOL if "q_bl" in self._keep else \
+            VK_POINTS_MIMC if "q_mimc_selector" in self._keep else VK_POINTS
         return {k: out[8 * i:8 * i + 8] for i, k in enumerate(names)}
 
     def challenges(self):
@@ -406,16 +408,17 @@ def hex4(limbs):
     return "%016x%016x%016x%016x" % (int(limbs[3]), int(limbs[2]), int(limbs[1]), int(limbs[0]))
 
 
-def proof_lines(n, proof, mimc=False):
-    """the text form oracle/plonk_driver.cpp prints and tests/golden/plonk_proofs.json stores (with the MiMC widget: two more evaluations)"""
+def proof_lines(n, proof, mimc=False, sequential=False):
+    """the text form oracle/plonk_driver.cpp prints and tests/golden/plonk_proofs.json stores (with the MiMC widget: two more evaluations,
+    with the sequential widget: w_o_shifted_eval)"""
     out = ["n %d" % n]
     for i, name in enumerate(PROOF_POINTS):
         out.append("%s.x %s" % (name, hex4(proof[8 * i:8 * i + 4])))
         out.append("%s.y %s" % (name, hex4(proof[8 * i + 4:8 * i + 8])))
     for i, name in enumerate(PROOF_EVALS):
         out.append("%s %s" % (name, hex4(proof[72 + 4 * i:76 + 4 * i])))
-    if mimc:
-        for name in ("w_o_shifted_eval", "q_mimc_coefficient_eval"):
+    if mimc or sequential:
+        for name in ("w_o_shifted_eval", "q_mimc_coefficient_eval")[:2 if mimc else 1]:
             i = PROOF_EVALS_WIDGET.index(name)
             out.append("%s %s" % (name, hex4(proof[100 + 4 * i:104 + 4 * i])))
     return out

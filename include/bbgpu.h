@@ -179,20 +179,26 @@ typedef struct {
      * widgets/mimc_widget.hpp): q_mimc_selector, q_mimc_coefficient (the round constants), n x 4 limbs each; NULL without it.
      * The proof then also carries w_o_shifted_eval and q_mimc_coefficient_eval. */
     const uint64_t *q_mimc_selector, *q_mimc_coefficient;
+    /* optional sequential widget (ExtendedComposer::preprocess(), extended_composer.cpp:460-607, widgets/sequential_widget.hpp): q_o_next,
+     * the selector of the NEXT gate's output wire in the arithmetic identity, n x 4 limbs; NULL without it.  May be combined with the
+     * bool widget (the ExtendedComposer's chain: arithmetic, sequential, bool), not with the MiMC widget.  The proof then carries
+     * w_o_shifted_eval. */
+    const uint64_t *q_o_next;
 } bbgpu_plonk_circuit;
 /* proof = waffle::plonk_proof (waffle_types.hpp:18-45) in its own field order: W_L, W_R, W_O, Z_1, T_LO, T_MID, T_HI,
  * PI_Z, PI_Z_OMEGA (affine x, y: 8 limbs each), then w_l_eval, w_r_eval, w_o_eval, sigma_1_eval, sigma_2_eval,
  * z_1_shifted_eval, linear_eval, and the widget-dependent w_l_shifted_eval, w_r_shifted_eval, w_o_shifted_eval, q_c_eval,
  * q_mimc_coefficient_eval (4 limbs each; zero unless a widget fills them: the MiMC widget sets w_o_shifted_eval and
- * q_mimc_coefficient_eval); Montgomery form, canonical -- byte-identical to the reference's proof */
+ * q_mimc_coefficient_eval, the sequential widget w_o_shifted_eval); Montgomery form, canonical -- byte-identical to the reference's proof */
 #define BBGPU_PLONK_PROOF_WORDS 120
 int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* circuit, int srs_handle); /* returns a prover handle >= 0 */
 int bbgpu_plonk_prover_set_witness(int prover, const uint64_t* w_l, const uint64_t* w_r, const uint64_t* w_o);
 int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF_WORDS]); /* Prover::construct_proof, prover.cpp:661-670 */
 /* waffle::preprocess(prover) (preprocess.hpp:16-55, arithmetic_widget.cpp:128-157, bool_widget.cpp:118-152): the verification key of
  * the circuit -- SIGMA_1, SIGMA_2, SIGMA_3, the commitments to q_m, q_l, q_r, q_o, q_c, and with the bool widget those to q_bl, q_br,
- * q_bo (affine x, y: 8 limbs each; 8 or 11 points -- pass room for 11) */
-#define BBGPU_PLONK_VK_WORDS 88
+ * q_bo, with the MiMC widget q_mimc_coefficient, q_mimc_selector, with the sequential widget q_o_next (before the bool widget's three) --
+ * affine x, y: 8 limbs each; 8 to 12 points, pass room for 12 */
+#define BBGPU_PLONK_VK_WORDS 96
 int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[BBGPU_PLONK_VK_WORDS]);
 int bbgpu_plonk_last_challenges(int prover, uint64_t out[20]); /* beta, gamma, alpha, z, nu (waffle_types.hpp:9-16) */
 int bbgpu_plonk_last_timing(int prover, double ms_out[4]);     /* construct_proof wall ms: total, in commitments, rest, first-use preparation */

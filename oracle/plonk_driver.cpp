@@ -21,6 +21,8 @@
 //   bits a_i, b_i constrained boolean, c_i = a_i b_i (mul gate), d_i = a_i + c_i (add gate)
 //   BB_CIRCUIT=mimc: a MiMCComposer circuit (arithmetic + MiMC widget): a chain of <num_gates> - 2 MiMC rounds x <- (x + k + c_i)^7 from fixed
 //   witnesses, then an addition gate on the result; the proof then carries w_o_shifted_eval and q_mimc_coefficient_eval as well
+//   BB_CIRCUIT=extended selects an ExtendedComposer circuit (arithmetic + sequential + bool widgets): products, pairs of chained additions
+//   that the composer folds into one gate with a q_o_next term, boolean constraints; the proof then carries w_o_shifted_eval
 //   plonk_xxx verify <num_gates> < proof       rebuild the same circuit's Verifier and check a proof given in the `prove` text
 //                                              format on stdin (used to verify proofs made by the native GPU prover)
 #include <barretenberg/curves/bn254/fq.hpp>
@@ -28,6 +30,7 @@
 #include <barretenberg/curves/bn254/g1.hpp>
 #include <barretenberg/curves/bn254/g2.hpp>
 #include <barretenberg/waffle/composer/bool_composer.hpp>
+#include <barretenberg/waffle/composer/extended_composer.hpp>
 #include <barretenberg/waffle/composer/mimc_composer.hpp>
 #include <barretenberg/waffle/composer/standard_composer.hpp>
 #include <barretenberg/waffle/proof_system/preprocess.hpp>
@@ -36,6 +39,7 @@
 #include <barretenberg/waffle/proof_system/widgets/arithmetic_widget.hpp>
 #include <barretenberg/waffle/proof_system/widgets/bool_widget.hpp>
 #include <barretenberg/waffle/proof_system/widgets/mimc_widget.hpp>
+#include <barretenberg/waffle/proof_system/widgets/sequential_widget.hpp>
 #include <barretenberg/waffle/stdlib/field/field.hpp>
 
 #include <arpa/inet.h>
@@ -130,6 +134,7 @@ int prove(size_t num_gates, bool trace)
         hex4(en[9], ev[9]->data);   // w_o_shifted_eval (prover.cpp:499-502)
         hex4(en[11], ev[11]->data); // q_mimc_coefficient_eval (mimc_widget.cpp:92-95)
     }
+    if (prover.widgets.size() > 1 && dynamic_cast<const waffle::ProverSequentialWidget*>(prover.widgets[1].get())) hex4(en[9], ev[9]->data);
     if (trace) {
         hex4("beta", prover.challenges.beta.data);
         hex4("gamma", prover.challenges.gamma.data);
@@ -193,9 +198,34 @@ void build_mimc_circuit(waffle::MiMCComposer& composer, size_t num_gates)
     const uint32_t sum_idx = composer.add_variable(fr::add(x, composer.get_variable(x0_idx)));
     composer.create_add_gate({ x_idx, x0_idx, sum_idx, fr::one, fr::one, fr::neg_one(), fr::zero });
 }
+// ExtendedComposer circuit (extended_composer.cpp): per block of 4 gates a product, two chained additions whose shared wire appears nowhere
+// else (combine_linear_relations() folds them into ONE gate with a q_o_next term, extended_composer.cpp:213-440) and a boolean constraint
+void build_extended_circuit(waffle::ExtendedComposer& composer, size_t num_gates)
+{
+    const fr::field_t one = fr::one, zero = fr::zero, minus_one = fr::neg_one();
+    fr::field_t a = fr::to_montgomery_form({ { 0x1111111122222222ULL, 0x3333333344444444ULL, 0x5555555566666666ULL, 0x0777777788888888ULL } });
+    fr::field_t b = fr::to_montgomery_form({ { 0x9999aaaabbbbccccULL, 0xddddeeeeffff0000ULL, 0x1234123412341234ULL, 0x0abcdefabcdefabcULL } });
+    for (size_t i = 0; i < num_gates / 4; ++i) {
+        const fr::field_t bit = ((i * 3 + 1) & 2) ? one : zero;
+        const fr::field_t c = fr::mul(a, b), e = fr::add(c, a), g = fr::add(e, bit);
+        const uint32_t ai = composer.add_variable(a), bi = composer.add_variable(b), ci = composer.add_variable(c);
+        const uint32_t ei = composer.add_variable(e), biti = composer.add_variable(bit), gi = composer.add_variable(g);
+        composer.create_mul_gate({ ai, bi, ci, one, minus_one, zero });
+        composer.create_add_gate({ ci, ai, ei, one, one, minus_one, zero });
+        composer.create_add_gate({ ei, biti, gi, one, one, minus_one, zero });
+        composer.create_bool_gate(biti);
+        a = fr::add(g, b);
+        b = fr::sqr(c);
+    }
+}
 std::unique_ptr<waffle::ComposerBase> make_circuit(size_t num_gates)
 {
     const char* kind = getenv("BB_CIRCUIT");
+    if (kind && !strcmp(kind, "extended")) {
+        auto c = std::make_unique<waffle::ExtendedComposer>(num_gates);
+        build_extended_circuit(*c, num_gates);
+        return c;
+    }
     if (kind && !strcmp(kind, "mimc")) {
         auto c = std::make_unique<waffle::MiMCComposer>(num_gates);
         build_mimc_circuit(*c, num_gates);
@@ -220,7 +250,9 @@ int dump(size_t num_gates, const char* path)
     const waffle::ProverArithmeticWidget* w = dynamic_cast<const waffle::ProverArithmeticWidget*>(prover.widgets[0].get());
     const waffle::ProverBoolWidget* wb = prover.widgets.size() > 1 ? dynamic_cast<const waffle::ProverBoolWidget*>(prover.widgets[1].get()) : nullptr;
     const waffle::ProverMiMCWidget* wm = prover.widgets.size() > 1 ? dynamic_cast<const waffle::ProverMiMCWidget*>(prover.widgets[1].get()) : nullptr;
-    if (!w || prover.widgets.size() > 2 || (prover.widgets.size() == 2 && !wb && !wm)) return 3;
+    const waffle::ProverSequentialWidget* ws = prover.widgets.size() == 3 ? dynamic_cast<const waffle::ProverSequentialWidget*>(prover.widgets[1].get()) : nullptr;
+    if (ws) wb = dynamic_cast<const waffle::ProverBoolWidget*>(prover.widgets[2].get()); // ExtendedComposer: arithmetic, sequential, bool
+    if (!w || prover.widgets.size() > 3 || (prover.widgets.size() == 2 && !wb && !wm) || (prover.widgets.size() == 3 && (!ws || !wb))) return 3;
     FILE* f = fopen(path, "wb");
     if (!f) return 1;
     const uint64_t n = prover.n;
@@ -240,6 +272,7 @@ int dump(size_t num_gates, const char* path)
         const barretenberg::polynomial* msel[2] = { &wm->q_mimc_selector, &wm->q_mimc_coefficient };
         for (auto* p : msel) wr(f, const_cast<barretenberg::polynomial*>(p)->get_coefficients(), n * 32);
     }
+    if (ws) wr(f, const_cast<barretenberg::polynomial&>(ws->q_o_next).get_coefficients(), n * 32); // sequential widget selector comes last
     fclose(f);
     printf("n %zu\n", (size_t)n);
     return 0;
@@ -264,7 +297,14 @@ int vk(size_t num_gates)
         snprintf(nm, sizeof nm, "%s.x", qn[i]); hex4(nm, inst[i].x.data);
         snprintf(nm, sizeof nm, "%s.y", qn[i]); hex4(nm, inst[i].y.data);
     }
-    if (verifier.verifier_widgets.size() > 1 && verifier.verifier_widgets[1]->instance.size() == 2) { // MiMC widget (mimc_widget.cpp:133-160)
+    if (verifier.verifier_widgets.size() == 3) { // ExtendedComposer: sequential widget (sequential_widget.cpp:79-106), then the bool widget
+        const char* xn[4] = { "Q_O_NEXT", "Q_BL", "Q_BR", "Q_BO" };
+        for (int i = 0; i < 4; i++) {
+            const auto& pt = i == 0 ? verifier.verifier_widgets[1]->instance[0] : verifier.verifier_widgets[2]->instance[i - 1];
+            snprintf(nm, sizeof nm, "%s.x", xn[i]); hex4(nm, pt.x.data);
+            snprintf(nm, sizeof nm, "%s.y", xn[i]); hex4(nm, pt.y.data);
+        }
+    } else if (verifier.verifier_widgets.size() > 1 && verifier.verifier_widgets[1]->instance.size() == 2) { // MiMC widget (mimc_widget.cpp:133-160)
         const char* mn[2] = { "Q_MIMC_COEFFICIENT", "Q_MIMC_SELECTOR" };
         const auto& minst = verifier.verifier_widgets[1]->instance;
         for (int i = 0; i < 2; i++) {
@@ -315,6 +355,9 @@ int verify(size_t num_gates)
     for (int i = 0; i < 7; i++) if (!rd4(en[i], ev[i]->data)) return 4;
     if (prover.widgets.size() > 1 && dynamic_cast<const waffle::ProverMiMCWidget*>(prover.widgets[1].get())) {
         if (!rd4("w_o_shifted_eval", proof.w_o_shifted_eval.data) || !rd4("q_mimc_coefficient_eval", proof.q_mimc_coefficient_eval.data)) return 4;
+    }
+    if (prover.widgets.size() > 1 && dynamic_cast<const waffle::ProverSequentialWidget*>(prover.widgets[1].get())) {
+        if (!rd4("w_o_shifted_eval", proof.w_o_shifted_eval.data)) return 4;
     }
     bool ok = verifier.verify_proof(proof);
     printf("verified %d\n", ok ? 1 : 0);

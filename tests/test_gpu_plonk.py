@@ -338,3 +338,48 @@ def test_resident_prover_with_mimc_widget(gpu, srs65536, golden, gates):
             assert r.returncode == 0 and r.stdout.strip() == "verified 1", (r.stdout, r.stderr[-500:])
     finally:
         prover.destroy()
+
+
+def _extended_state(gates):
+    """the waffle::Prover input state the reference's ExtendedComposer produced for the fixture circuit (data, tools/gen_plonk_golden.py)"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "plonk_extended_state.npz"))
+    st = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("%d/" % gates)}
+    st["n"] = int(st["n"][0])
+    return st
+
+
+@pytest.mark.parametrize("gates", [8, 32, 100, 160])
+def test_resident_prover_with_sequential_and_bool_widgets(gpu, srs65536, golden, gates):
+    """the ExtendedComposer's widget chain -- arithmetic, sequential (q_o_next * w_o at the next row, sequential_widget.cpp), bool -- on the
+    resident prover.  The composer's gate folding is not mirrored: the Prover input state the reference composer produced is the fixture.
+    Proof bytes (27 lines, with w_o_shifted_eval), all five challenges and the verification key (12 commitments) equal the reference's; its
+    Verifier accepts the proof."""
+    from barretenberg_amd.plonk import VK_POINTS_EXTENDED, Prover, hex4, proof_lines
+    from oracle.pyoracle import Oracle
+    fx = golden("plonk_trace.json")["extended"]
+    state = _extended_state(gates)
+    assert any(int(v) for v in state["q_o_next"].ravel()) and any(int(v) for v in state["q_br"].ravel())  # both extra widgets are exercised
+    prover = Prover(gpu, state, srs65536)
+    try:
+        proof = prover.construct_proof()
+        got = proof_lines(state["n"], proof, sequential=True)
+        ch = prover.challenges()
+        for name in ("gamma", "beta", "alpha", "z", "nu"):
+            assert hx(ch[name])[0] == fx["challenges"][str(gates)][name], name
+        assert got == fx["proofs"][str(gates)][:27]
+        vk = prover.preprocess()
+        ref = {ln.split()[0]: ln.split()[1] for ln in fx["verification_keys"][str(gates)][1:]}
+        for k in VK_POINTS_EXTENDED:
+            if int(vk[k][7]) >> 63:  # commitment to a zero selector: see the arithmetic-widget test
+                rp = np.array([int(ref[k + c][16 * (3 - j):16 * (4 - j)], 16) for c in (".x", ".y") for j in range(4)], dtype=np.uint64)
+                assert not Oracle().g1_on_curve(rp), k
+                continue
+            assert hex4(vk[k][0:4]) == ref[k + ".x"] and hex4(vk[k][4:8]) == ref[k + ".y"], k
+        assert np.array_equal(prover.construct_proof(), proof)
+        exe = os.path.join(ROOT, "oracle", "_ref", "plonk_cpu")
+        if os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "transcript.dat")):
+            r = subprocess.run([exe, "verify", str(gates)], input="\n".join(got) + "\n", cwd=ROOT, capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, OMP_NUM_THREADS="16", BB_CIRCUIT="extended"))
+            assert r.returncode == 0 and r.stdout.strip() == "verified 1", (r.stdout, r.stderr[-500:])
+    finally:
+        prover.destroy()

@@ -3,6 +3,7 @@ composer's output, and the Fiat-Shamir transcript (Keccak-256 + host fr/fq arith
 challenges the reference's prover derived for the golden proofs."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -11,6 +12,7 @@ from barretenberg_amd import BbGpu
 from barretenberg_amd.plonk import bench_circuit, proof_from_lines, proof_lines
 
 MAPS = ("sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -101,3 +103,28 @@ def test_mimc_composer_noop_and_closing_gates():
     assert c.n == 3 and c.w_o == [a, a7, b] and c.q_mimc_selector == [1, 0, 1]
     st = c.preprocess()  # closing gate for b7
     assert st["n"] == 4 and c.w_o[3] == b7 and c.w_l[3] == c.zero_idx
+
+
+@pytest.mark.parametrize("gates", [8, 32, 100, 160])
+def test_extended_composer_state_fixture_is_a_satisfied_circuit(gates):
+    """tests/golden/plonk_extended_state.npz (the reference ExtendedComposer's Prover input state) read with the plain numpy loader: every
+    row satisfies the extended arithmetic identity q_m w_l w_r + q_l w_l + q_r w_r + q_o w_o + q_c + q_o_next w_o[i+1] = 0
+    (arithmetic_widget.cpp:66-104 + sequential_widget.cpp:47-62) and the boolean constraints, and the sigma mappings are permutations"""
+    from oracle.pyoracle import FR_MODULUS
+    z = np.load(os.path.join(ROOT, "tests", "golden", "plonk_extended_state.npz"))
+    st = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("%d/" % gates)}
+    n = int(st["n"][0])
+    rinv = pow(1 << 256, -1, FR_MODULUS)
+
+    def vals(k):
+        return [sum(int(v) << (64 * j) for j, v in enumerate(row)) * rinv % FR_MODULUS for row in st[k]]
+    wl, wr, wo = vals("w_l"), vals("w_r"), vals("w_o")
+    q = {k: vals(k) for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "q_bl", "q_br", "q_bo", "q_o_next")}
+    assert any(q["q_o_next"]) and any(q["q_br"])
+    for i in range(n):
+        lhs = q["q_m"][i] * wl[i] * wr[i] + q["q_l"][i] * wl[i] + q["q_r"][i] * wr[i] + q["q_o"][i] * wo[i] + q["q_c"][i] + q["q_o_next"][i] * wo[(i + 1) % n]
+        assert lhs % FR_MODULUS == 0, i
+        for sel, w in ((q["q_bl"], wl), (q["q_br"], wr), (q["q_bo"], wo)):
+            assert sel[i] * (w[i] * w[i] - w[i]) % FR_MODULUS == 0, i
+    ids = sorted(int(v) for k in ("sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping") for v in st[k])
+    assert ids == sorted(i + (t << 30) for t in range(3) for i in range(n))

@@ -114,6 +114,34 @@ def main():
             dig[k] = hashlib.sha256(b[o:o + 32 * n]).hexdigest(); o += 32 * n
         out["mimc"]["input_digests"][str(gates)] = dig
         os.remove(path)
+    # ExtendedComposer circuit (arithmetic + sequential + bool widgets; `BB_CIRCUIT=extended plonk_cpu ...`).  The 700-line composer (gate
+    # folding) is not mirrored in Python: the waffle::Prover INPUT state it produces (`plonk_cpu dump`) is stored as data in
+    # tests/golden/plonk_extended_state.npz and handed to the resident prover as it is.
+    xenv = dict(os.environ, BB_CIRCUIT="extended")
+    xsel = SELECTORS + ("q_bl", "q_br", "q_bo", "q_o_next")
+    out["extended"] = {"proofs": {}, "challenges": {}, "verification_keys": {}}
+    xstate = {}
+    for gates in (8, 32, 100, 160):  # n = 8, 32, 64, 128
+        lines = subprocess.run([EXE, "trace", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True, env=xenv).stdout.strip().split("\n")
+        out["extended"]["challenges"][str(gates)] = {ln.split()[0]: ln.split()[1] for ln in lines if ln.split()[0] in ("beta", "gamma", "alpha", "z", "nu")}
+        out["extended"]["proofs"][str(gates)] = [ln for ln in lines if ln.split()[0] not in ("beta", "gamma", "alpha", "z", "nu")]
+        out["extended"]["verification_keys"][str(gates)] = subprocess.run([EXE, "vk", str(gates)], cwd=ROOT, capture_output=True, text=True, check=True,
+                                                                          env=xenv).stdout.strip().split("\n")
+        path = "/tmp/plonk_dump_ext_%d.bin" % gates
+        subprocess.run([EXE, "dump", str(gates), path], cwd=ROOT, check=True, stdout=subprocess.DEVNULL, env=xenv)
+        b = open(path, "rb").read()
+        n = int.from_bytes(b[8:16], "little")
+        o = 16
+        xstate["%d/n" % gates] = np.array([n], dtype=np.uint64)
+        for k in FIELDS64:
+            xstate["%d/%s" % (gates, k)] = np.frombuffer(b, dtype=np.uint64, count=4 * n, offset=o).reshape(n, 4).copy(); o += 32 * n
+        for k in MAPS:
+            xstate["%d/%s" % (gates, k)] = np.frombuffer(b, dtype=np.uint32, count=n, offset=o).copy(); o += 4 * n
+        for k in xsel:
+            xstate["%d/%s" % (gates, k)] = np.frombuffer(b, dtype=np.uint64, count=4 * n, offset=o).reshape(n, 4).copy(); o += 32 * n
+        assert o == len(b)
+        os.remove(path)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "plonk_extended_state.npz"), **xstate)
     if not big:  # keep the large-circuit entries of an earlier run
         old = json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_trace.json")))
         for key in ("challenges", "input_digests", "verification_keys"):
