@@ -156,31 +156,38 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
                 x2.d[l] = lds[l * E + e2];
                 x3.d[l] = lds[l * E + e3];
             }
-            // stage s
-            Fe<Fr, 2, NTT_VMAX + 3> a0, a2;
-            Fe<Fr, 4, NTT_VMAX + 4> a1, a3;
-            if (s == 0) { // twiddle one
-                // value bound: inputs come straight from unpack()/pre-scale (< 6p), so x +- y stays far below NTT_VMAX
-                a0 = assume_bound<2, NTT_VMAX + 3>(add(x0, x1));
-                a1 = assume_bound<4, NTT_VMAX + 4>(sub(x0, x1));
-                a2 = assume_bound<2, NTT_VMAX + 3>(add(x2, x3));
-                a3 = assume_bound<4, NTT_VMAX + 4>(sub(x2, x3));
+            FrL y0, y1, y2, y3;
+            if (s == 0) { // first pair: stage 0 has twiddle one everywhere, stage 1 has twiddle one on (e0, e2): ONE multiplication for the group
+                // value bound: inputs come straight from unpack()/pre-scale (< 6p), so the four sums stay far below NTT_VMAX
+                using In = Fe<Fr, 1, 6>; // what unpack() / the pre-scale product really hold
+                const In z0 = assume_bound<1, 6>(x0), z1 = assume_bound<1, 6>(x1), z2 = assume_bound<1, 6>(x2), z3 = assume_bound<1, 6>(x3);
+                const auto a0 = add(z0, z1);
+                const auto a1 = sub(z0, z1);
+                const auto a2 = add(z2, z3);
+                const auto a3 = sub(z2, z3);
+                const FeT<Fr> w4 = load_tw(A.tw_sub, 1u << (A.log_s - 2)); // w_S^(S/4)
+                const auto u3 = mul(w4, a3);                               // < 3p
+                y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, a2)));
+                y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, a2)));
+                y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
+                y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
             } else {
+                // stage s
                 const FeT<Fr> w1 = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
                 const auto t1 = mul(w1, x1), t3 = mul(w1, x3); // < 3p
-                a0 = add(x0, t1);
-                a1 = sub(x0, t1);
-                a2 = add(x2, t3);
-                a3 = sub(x2, t3);
+                const auto a0 = add(x0, t1);
+                const auto a1 = sub(x0, t1);
+                const auto a2 = add(x2, t3);
+                const auto a3 = sub(x2, t3);
+                // stage s+1
+                const FeT<Fr> w2a = load_tw(A.tw_sub, j << (A.log_s - 2 - s));
+                const FeT<Fr> w2b = load_tw(A.tw_sub, (j + m) << (A.log_s - 2 - s));
+                const auto u2 = mul(w2a, a2), u3 = mul(w2b, a3); // < 3p
+                y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, u2)));
+                y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, u2)));
+                y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
+                y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
             }
-            // stage s+1
-            const FeT<Fr> w2a = load_tw(A.tw_sub, j << (A.log_s - 2 - s));
-            const FeT<Fr> w2b = load_tw(A.tw_sub, (j + m) << (A.log_s - 2 - s));
-            const auto u2 = mul(w2a, a2), u3 = mul(w2b, a3); // < 3p
-            const FrL y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, u2)));
-            const FrL y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, u2)));
-            const FrL y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
-            const FrL y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 lds[l * E + e0] = y0.d[l];
