@@ -778,7 +778,12 @@ constexpr uint32_t MIN_CHUNK = 8;
 static uint32_t chunk_len(size_t n, uint32_t nw)
 {
     const uint64_t m = (uint64_t)n * nw;
-    const uint32_t cap = acc_capacity_lanes();
+    static int waves = 0; // BBGPU_ACC_WAVES: k > 1 cuts the list into k times as many (shorter) chunks -> k waves of workgroups (tuning experiments)
+    if (!waves) {
+        waves = 1;
+        if (const char* e = getenv("BBGPU_ACC_WAVES")) waves = std::min(16, std::max(1, atoi(e)));
+    }
+    const uint64_t cap = (uint64_t)acc_capacity_lanes() * (uint64_t)waves;
     uint32_t ch = (uint32_t)((m + cap - 1) / cap);
     return ch < MIN_CHUNK ? MIN_CHUNK : ch;
 }
