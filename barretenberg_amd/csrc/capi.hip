@@ -300,7 +300,7 @@ int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* con
     if (rc) return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
     rc = ntt_device(d_coeffs, g_ctx.d_scratch, lg, kind, constant, st);
-    if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^22)", lg);
+    if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^28)", lg);
     if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
     return rc;
 }
@@ -323,7 +323,7 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
     if (rc) return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
     rc = ntt_device_batch(d_coeffs, stride_elems, batch, g_ctx.d_scratch, lg, kind, constant, st);
-    if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^22)", lg);
+    if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^28)", lg);
     if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
     return rc;
 }
@@ -418,7 +418,7 @@ int bbgpu_lagrange_l1_fft_device(uint64_t* d_l_1, size_t n_src, size_t n_target,
 {
     POLY_ENTER(d_l_1);
     const int ls = log2_exact(n_src), lt = log2_exact(n_target);
-    if (ls < 1 || lt < ls || lt > 22) {
+    if (ls < 1 || lt < ls || lt > 28) {
         set_error("lagrange_l1_fft: domains must be powers of two, target >= source");
         return BBGPU_ERR_SIZE;
     }
@@ -431,7 +431,7 @@ int bbgpu_divide_by_pseudo_vanishing_device(uint64_t* d_coeffs, size_t n_src, si
 {
     POLY_ENTER(d_coeffs);
     const int ls = log2_exact(n_src), lt = log2_exact(n_target);
-    if (ls < 1 || lt < ls || lt > 22) {
+    if (ls < 1 || lt < ls || lt > 28) {
         set_error("divide_by_pseudo_vanishing: domains must be powers of two, target >= source");
         return BBGPU_ERR_SIZE;
     }
@@ -442,7 +442,7 @@ int bbgpu_permutation_lagrange_base_device(uint64_t* d_out, const uint32_t* d_ma
 {
     POLY_ENTER(d_out && d_mapping);
     const int lg = log2_exact(n);
-    if (lg < 1 || lg > 22) return BBGPU_ERR_SIZE;
+    if (lg < 1 || lg > 28) return BBGPU_ERR_SIZE;
     int rc = grow(&g_ctx.d_poly_tmp, &g_ctx.poly_tmp_cap, n * 32);
     if (rc) return rc;
     rc = poly::powers(g_ctx.d_poly_tmp, n, host::fr_root_of_unity(lg), host::fr_one(), st);

@@ -32,6 +32,7 @@ namespace bbgpu {
 using Fr = FrP;
 constexpr int NTT_VMAX = 48;                 // lazy value bound inside one pass: 6 + 3 * 12 stages + slack
 using FrL = Fe<Fr, 1, NTT_VMAX>;             // LDS-resident element
+constexpr int NTT_MAX_LOG2N = 28;            // two-adicity of r - 1 (fr.hpp:60-63): the largest domain the reference has a root for
 constexpr int NTT_MAX_LOG_SUB = 11;          // sub-transform up to 2048 points (72 KiB of LDS)
 constexpr int NTT_LDS_ELEMS = 2048;          // elements of LDS per workgroup (9 words each = 72 KiB) -> 2 WG / CU
 constexpr int NTT_THREADS = 512;
@@ -99,6 +100,7 @@ struct NttPassArgs {
     uint32_t xcd_remap;       // 1: contiguous tile range per XCD (see ntt_pass_kernel)
     uint32_t batch;           // transforms in this launch (blockIdx.y): transform j works on in + j * in_bstride -> out + j * out_bstride
     size_t in_bstride, out_bstride; // in words
+    uint32_t nat_bstep;       // natural output index of batch item j starts at j * nat_bstep (three-pass transforms: rows of one big transform; else 0)
 };
 
 // FLAGS: 1 = pre-scale input by scale tables (coset_fft), 2 = twist output (pass 1 of 2),
@@ -250,11 +252,11 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
         } else {
             Fe<Fr, 1, 3> r;
             if constexpr ((FLAGS & 4) && (FLAGS & 8)) {
-                const uint32_t i = (uint32_t)gidx;
+                const uint32_t i = (uint32_t)gidx + blockIdx.y * A.nat_bstep;
                 auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
                 r = mul(mul(x, g), fe_from<Fr>(A.post_const));
             } else if constexpr (FLAGS & 4) {
-                const uint32_t i = (uint32_t)gidx;
+                const uint32_t i = (uint32_t)gidx + blockIdx.y * A.nat_bstep;
                 auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
                 r = mul(x, g);
             } else if constexpr (FLAGS & 8) {
@@ -313,6 +315,7 @@ struct DomainTables {
     int log2n = -1;
     int log_s1 = 0, log_s2 = 0, lo_bits = 0;
     uint32_t* tw_sub[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } }; // [inverse][pass]
+    uint32_t* tw_sub3[2] = { nullptr, nullptr };                             // [inverse]: pass A of a three-pass transform (n > 2^22)
     uint32_t* twist_lo[2] = { nullptr, nullptr };                            // [inverse]
     uint32_t* twist_hi[2] = { nullptr, nullptr };
     uint32_t* scale_lo[2] = { nullptr, nullptr };                            // [0]: g^i, [1]: g^-i * n^-1
@@ -342,6 +345,8 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
         D->log_s2 = log2n / 2;
         D->log_s1 = log2n - D->log_s2;
     }
+    const bool three = log2n > 2 * NTT_MAX_LOG_SUB;
+    if (three) D->log_s1 = D->log_s2 = 0; // the row transforms use the tables of their own (size-m) domain
     D->lo_bits = (log2n + 1) / 2;
     const H one = fe_one<Fr>();
     H root = h_pow2k(h_from(Fr::ROOT28), 28 - log2n);          // w_n   (field.hpp:487-494 semantics)
@@ -363,6 +368,10 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
             H ws = h_pow2k(w, log2n - logs[p]);
             uint32_t cnt = logs[p] >= 1 ? (1u << (logs[p] - 1)) : 1;
             if ((e = pow_table(&D->tw_sub[inv][p], cnt, ws, one, st)) != hipSuccess) return e;
+        }
+        if (three) { // w_n1 = w_n^(n / n1), n1 = 2^(log2n - 2 (log2n / 3))
+            const int l1 = log2n - 2 * (log2n / 3);
+            if ((e = pow_table(&D->tw_sub3[inv], 1u << (l1 - 1), h_pow2k(w, log2n - l1), one, st)) != hipSuccess) return e;
         }
         if ((e = pow_table(&D->twist_lo[inv], 1u << D->lo_bits, w, one, st)) != hipSuccess) return e;
         if ((e = pow_table(&D->twist_hi[inv], 1u << (log2n - D->lo_bits), h_pow2k(w, D->lo_bits), one, st)) != hipSuccess) return e;
@@ -423,6 +432,83 @@ hipError_t dispatch(int flags, const NttPassArgs& A, hipStream_t st)
 
 } // namespace
 
+// n = 2^23 .. 2^28 (the field's two-adicity, fr.hpp:60-63): n = n1 * m, three passes over HBM
+//   A: for every column j' < m: n1-point transform over j1 (stride m) IN PLACE (a workgroup owns whole columns), twist by w_n^(k1 j')
+//   B, C: for every row k1 < n1: the m-point transform of the contiguous row (the two-pass scheme above with the tables of the size-m
+//         domain, w_m = w_n^n1), rows side by side in one launch (blockIdx.y = k1); results land transposed: X[k1 + n1 k']
+// Coset pre-scaling rides on pass A's load, post-scaling / constants on pass C's store (natural index k1 + n1 k').
+static int ntt_device_three_pass(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256, hipStream_t st)
+{
+    const int lm = 2 * (log2n / 3), l1 = log2n - lm; // row transforms split evenly; every sub-transform <= 2^10
+    DomainTables *D, *Dm;
+    if (get_domain(log2n, st, &D) != hipSuccess || get_domain(lm, st, &Dm) != hipSuccess) return BBGPU_ERR_HIP;
+    const bool inverse = (kind == BBGPU_IFFT || kind == BBGPU_COSET_IFFT || kind == BBGPU_IFFT_WITH_CONSTANT);
+    const bool pre = (kind == BBGPU_COSET_FFT || kind == BBGPU_COSET_FFT_WITH_CONSTANT);
+    const bool post_table = (kind == BBGPU_COSET_IFFT);
+    const bool has_const = (kind == BBGPU_FFT_WITH_CONSTANT || kind == BBGPU_IFFT_WITH_CONSTANT || kind == BBGPU_COSET_FFT_WITH_CONSTANT);
+    if (has_const && !constant_m256) return BBGPU_ERR_ARG;
+    bool post_const = false;
+    H pc = fe_one<Fr>();
+    if (has_const) {
+        uint32_t w[8];
+        for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)constant_m256[i]; w[2 * i + 1] = (uint32_t)(constant_m256[i] >> 32); }
+        pc = m256_to_m261<Fr>(unpack<Fr>(w));
+        post_const = true;
+    }
+    if (kind == BBGPU_IFFT || kind == BBGPU_IFFT_WITH_CONSTANT) {
+        pc = mul(pc, fe_from<Fr>(D->n_inv.d));
+        post_const = true;
+    }
+    const Limbs9 pcl = to_limbs(pc);
+    const uint32_t n1 = 1u << l1, m = 1u << lm, m1 = 1u << Dm->log_s1, m2 = 1u << Dm->log_s2;
+    NttPassArgs A{};
+    A.xcd_remap = 1;
+    for (int i = 0; i < NL; i++) A.post_const[i] = pcl.d[i];
+    hipError_t e;
+    // pass A: columns of the n1 x m matrix, in place
+    A.batch = 1;
+    A.in = (const uint32_t*)d_coeffs;
+    A.out = (uint32_t*)d_coeffs;
+    A.tw_sub = D->tw_sub3[inverse] ;
+    A.lo_bits = D->lo_bits;
+    A.twist_lo = D->twist_lo[inverse]; A.twist_hi = D->twist_hi[inverse];
+    A.scale_lo = D->scale_lo[0]; A.scale_hi = D->scale_hi[0];
+    A.log_s = (uint32_t)l1; A.log_b = (uint32_t)lm;
+    A.cols = NTT_LDS_ELEMS >> l1; if (A.cols > m) A.cols = m;
+    A.log_cols = 31 - __builtin_clz(A.cols);
+    A.in_sa = m; A.in_sb = 1; A.out_sa = m; A.out_sb = 1; A.b_fast = 1;
+    if ((e = dispatch(2 | (pre ? 1 : 0), A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    // pass B: columns of every row's m1 x m2 matrix, coeffs -> scratch (same layout), twist by w_m^(k j)
+    A.batch = n1;
+    A.in = (const uint32_t*)d_coeffs;
+    A.out = (uint32_t*)d_scratch;
+    A.in_bstride = A.out_bstride = (size_t)m * 8;
+    A.tw_sub = Dm->tw_sub[inverse][0];
+    A.lo_bits = Dm->lo_bits;
+    A.twist_lo = Dm->twist_lo[inverse]; A.twist_hi = Dm->twist_hi[inverse];
+    A.log_s = Dm->log_s1; A.log_b = Dm->log_s2;
+    A.cols = NTT_LDS_ELEMS >> Dm->log_s1; if (A.cols > m2) A.cols = m2;
+    A.log_cols = 31 - __builtin_clz(A.cols);
+    A.in_sa = m2; A.in_sb = 1; A.out_sa = m2; A.out_sb = 1; A.b_fast = 1;
+    if ((e = dispatch(2, A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    // pass C: rows of every row's matrix, scratch -> coeffs; element k' = k1m + m1 k2m of row k1 goes to X[k1 + n1 k']
+    A.in = (const uint32_t*)d_scratch;
+    A.out = (uint32_t*)d_coeffs;
+    A.in_bstride = (size_t)m * 8;
+    A.out_bstride = 8;   // row k1 starts one element further
+    A.nat_bstep = 1;
+    A.tw_sub = Dm->tw_sub[inverse][1];
+    A.lo_bits = D->lo_bits; // the post-scale tables are those of the size-n domain
+    A.scale_lo = D->scale_lo[post_table ? 1 : 0]; A.scale_hi = D->scale_hi[post_table ? 1 : 0];
+    A.log_s = Dm->log_s2; A.log_b = Dm->log_s1;
+    A.cols = NTT_LDS_ELEMS >> Dm->log_s2; if (A.cols > m1) A.cols = m1;
+    A.log_cols = 31 - __builtin_clz(A.cols);
+    A.in_sa = 1; A.in_sb = m2; A.out_sa = m1 * n1; A.out_sb = n1; A.b_fast = 0;
+    const int last_flags = 16 | (post_table ? 4 : 0) | (post_const ? 8 : 0);
+    if ((e = dispatch(last_flags, A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    return BBGPU_OK;
+}
+
 // kind: bbgpu_ntt_kind; d_coeffs: n x 32 B device buffer, transformed in place; d_scratch: n x 32 B (only n > 2^11)
 int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256, hipStream_t st)
 {
@@ -435,7 +521,15 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
                      hipStream_t st)
 {
     if (batch < 1) return BBGPU_ERR_ARG;
-    if (log2n < 1 || log2n > 2 * NTT_MAX_LOG_SUB) return BBGPU_ERR_SIZE;
+    if (log2n < 1 || log2n > NTT_MAX_LOG2N) return BBGPU_ERR_SIZE;
+    if (log2n > 2 * NTT_MAX_LOG_SUB) { // three HBM passes, one transform at a time
+        if (!d_scratch) return BBGPU_ERR_ARG;
+        for (int j = 0; j < batch; j++) {
+            const int rc = ntt_device_three_pass(d_coeffs + (size_t)j * stride_elems * 4, d_scratch, log2n, kind, constant_m256, st);
+            if (rc != BBGPU_OK) return rc;
+        }
+        return BBGPU_OK;
+    }
     DomainTables* D;
     if (get_domain(log2n, st, &D) != hipSuccess) return BBGPU_ERR_HIP;
     const bool inverse = (kind == BBGPU_IFFT || kind == BBGPU_COSET_IFFT || kind == BBGPU_IFFT_WITH_CONSTANT);
@@ -520,6 +614,7 @@ void ntt_release_tables()
         DomainTables* D = kv.second;
         for (int i = 0; i < 2; i++) {
             for (int p = 0; p < 2; p++) if (D->tw_sub[i][p]) (void)hipFree(D->tw_sub[i][p]);
+            if (D->tw_sub3[i]) (void)hipFree(D->tw_sub3[i]);
             if (D->twist_lo[i]) (void)hipFree(D->twist_lo[i]);
             if (D->twist_hi[i]) (void)hipFree(D->twist_hi[i]);
             if (D->scale_lo[i]) (void)hipFree(D->scale_lo[i]);

@@ -26,7 +26,7 @@ extern "C" {
 enum {
     BBGPU_OK = 0,
     BBGPU_ERR_HIP = -1,   /* a HIP runtime call failed (no device, out of memory, launch failure) */
-    BBGPU_ERR_SIZE = -2,  /* size not supported (NTT: n must be 2^k, 2 <= n <= 2^22) */
+    BBGPU_ERR_SIZE = -2,  /* size not supported (NTT: n must be 2^k, 2 <= n <= 2^28 = the two-adicity of the field) */
     BBGPU_ERR_ARG = -3,   /* null pointer / bad enum / unknown handle */
     BBGPU_ERR_STATE = -4  /* library not initialised */
 };

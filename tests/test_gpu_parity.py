@@ -129,6 +129,43 @@ def test_ntt_linearity_full_size(gpu, oracle):
         assert np.array_equal(ff[i], oracle.add(FR, fa[i], fd[i]))
 
 
+def test_ntt_three_pass_vs_oracle(gpu, oracle, const):
+    """n = 2^23: above the two-pass limit (three HBM passes: columns in place, then batched row transforms); the pre-scaled and the
+    post-scaled variant (plain fft / ifft are covered by the next test)"""
+    n = 1 << 23
+    co = noncanonical(oracle.random_scalars(NTT_SEED + 23, n), FR_MODULUS)
+    for kind in ("coset_fft_with_constant", "coset_ifft"):
+        want = oracle.ntt(co, kind, const)
+        got = gpu.ntt(co.copy(), kind, const)
+        assert np.array_equal(got, want), kind
+
+
+def test_ntt_three_pass_consistent_with_two_pass_and_direct_evaluation(gpu, oracle):
+    """2^24: (i) the transform of a zero-padded 2^22-coefficient polynomial on the 4x larger domain agrees with the two-pass 2^22 transform
+    on the shared points (test_polynomial_arithmetic.cpp:130-175 at the largest sizes), (ii) sampled outputs equal Horner evaluation at
+    w^k, (iii) ifft(fft(x)) == x and coset_ifft(coset_fft(x)) == x"""
+    n = 1 << 22
+    base = oracle.random_scalars(2424, n)
+    small = gpu.fft(base.copy())
+    buf = np.zeros((4 * n, 4), dtype=np.uint64)
+    buf[:n] = base
+    big = gpu.fft(buf.copy())
+    assert np.array_equal(big[::4], small)
+    root = oracle.root_of_unity(24)
+    for k in (1, 3, (1 << 23) + 5, (1 << 24) - 1):
+        w = oracle.const(FR, "one")
+        b, e = root, k
+        while e:  # w = root^k
+            if e & 1:
+                w = oracle.mul(FR, w, b)
+            b = oracle.mul(FR, b, b)
+            e >>= 1
+        assert np.array_equal(big[k], oracle.evaluate(base, w)), k
+    x = oracle.random_scalars(2425, 4 * n)
+    assert np.array_equal(gpu.ifft(gpu.fft(x.copy())), x)
+    assert np.array_equal(gpu.coset_ifft(gpu.coset_fft(x.copy())), x)
+
+
 def test_ntt_rejects_bad_sizes(gpu):
     from barretenberg_amd import BbGpuError
     with pytest.raises(BbGpuError):

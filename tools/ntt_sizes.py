@@ -6,7 +6,7 @@ import numpy as np, torch
 from barretenberg_amd import BbGpu
 G = BbGpu(0)
 s = torch.cuda.Stream()
-for lg in (12, 14, 16, 18, 20, 21, 22):
+for lg in (12, 14, 16, 18, 20, 21, 22, 23, 24, 26):
     n = 1 << lg
     x = np.random.default_rng(lg).integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
     d = torch.from_numpy(x.view(np.int64)).cuda()
