@@ -709,8 +709,8 @@ int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* c, int srs_handle)
         set_error("MiMC widget selectors: give both q_mimc_selector and q_mimc_coefficient or neither, and not together with the bool or the sequential widget");
         return BBGPU_ERR_ARG;
     }
-    if (c->n < 4 || (c->n & (c->n - 1)) || c->n > ((size_t)1 << 20)) {
-        set_error("circuit size %zu: must be a power of two, 4 <= n <= 2^20 (the 4n transforms go up to 2^22)", c->n);
+    if (c->n < 4 || (c->n & (c->n - 1)) || c->n > ((size_t)1 << 22)) {
+        set_error("circuit size %zu: must be a power of two, 4 <= n <= 2^22 (the power tables of the pointwise kernels index 4n < 2^24 + 1 rows)", c->n);
         return BBGPU_ERR_SIZE;
     }
     const int W = bbgpu_srs_num_windows(srs_handle, c->n);

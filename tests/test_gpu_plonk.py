@@ -173,13 +173,13 @@ def srs_for(gpu, srs65536):
         gpu.srs_release(h)
 
 
-@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536, 262144, 1048576])
+@pytest.mark.parametrize("gates", [32, 1024, 16384, 65536, 262144, 1048576, 2097152])
 def test_resident_prover_proof_is_byte_identical(gpu, srs_for, golden, gates):
     """BASELINE config 5, natively: the bench_plonk.cpp add/mul-chain circuit built by the StandardComposer mirror (its state is
     pinned against the reference composer in tests/test_plonk_host.py), proved by bbgpu_plonk_construct_proof with all
     polynomials resident, against the proof the reference's all-CPU prover made for the same circuit, witnesses and SRS.
-    2^18 and 2^20 gates (the largest size the 4n = 2^22 transforms allow) use the same fixtures; the reference needed 3.7 s / 13.6 s
-    for them on 8 cores (tools/gen_plonk_golden.py)."""
+    2^18 and 2^20 gates use the same fixtures; the reference needed 3.7 s / 13.6 s for them on 8 cores (tools/gen_plonk_golden.py).
+    2^21 gates: the 4n = 2^23 transforms take the three-pass NTT and the 2^21-point commitments run without window tables."""
     from barretenberg_amd.plonk import Prover, bench_circuit, proof_lines
     tr = golden("plonk_trace.json")
     state = bench_circuit(gates, int(tr["witness_a0"], 16), int(tr["witness_b0"], 16)).preprocess()

@@ -49,7 +49,7 @@ def main():
     big = os.environ.get("BBGPU_BIG_SRS_DIR")
     proofs_path = os.path.join(ROOT, "tests", "golden", "plonk_proofs.json")
     proofs = json.load(open(proofs_path))
-    for gates in (32, 1024, 16384, 65536) + ((262144, 1048576) if big else ()):
+    for gates in (32, 1024, 16384, 65536) + ((262144, 1048576, 2097152) if big else ()):  # 2^21 gates: 4n = 2^23 transforms (three-pass NTT), needs a 2^21-point transcript
         r = subprocess.run([EXE, "trace", str(gates)], cwd=big if gates > 65536 else ROOT, capture_output=True, text=True, check=True)
         lines = r.stdout.strip().split("\n")
         if gates > 65536:
