@@ -456,3 +456,24 @@ def test_reference_prover_runs_on_gpu_bit_exact(golden, gates, build):
     want = golden("plonk_proofs.json")["proofs"][str(gates)]
     assert got == want
     assert got[-1] == "verified 1"
+
+
+@pytest.mark.parametrize("kind,gates", [("bool", 4096), ("mimc", 4094), ("extended", 160)])
+def test_reference_prover_other_composers_on_gpu_bit_exact(golden, kind, gates):
+    """the same link (plonk_gpu_full: every hot-path function from the shim) for the reference's BoolComposer, MiMCComposer and
+    ExtendedComposer circuits -- their widgets call the same fft / coset_fft / batched_scalar_multiplications entry points
+    (bool_widget.cpp:64-74,118-152, mimc_widget.cpp:60-67,125-160, sequential_widget.cpp:49-54,79-106): proofs byte-identical to the
+    all-CPU build's, and verified by the reference Verifier"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "plonk_gpu_full")
+    srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
+    if not (os.path.exists(exe) and os.path.exists(srs)):
+        pytest.skip("oracle/_ref/plonk_gpu_full not built (needs /root/reference at build time)")
+    env = dict(os.environ, OMP_NUM_THREADS="16", BB_CIRCUIT=kind)
+    r = subprocess.run([exe, "prove", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = r.stdout.strip().split("\n")
+    assert got == golden("plonk_trace.json")[kind]["proofs"][str(gates)]
+    assert got[-1] == "verified 1"
