@@ -23,6 +23,8 @@
 //   witnesses, then an addition gate on the result; the proof then carries w_o_shifted_eval and q_mimc_coefficient_eval as well
 //   BB_CIRCUIT=extended selects an ExtendedComposer circuit (arithmetic + sequential + bool widgets): products, pairs of chained additions
 //   that the composer folds into one gate with a q_o_next term, boolean constraints; the proof then carries w_o_shifted_eval
+//   plonk_gpu adapter <num_gates>              the level-2 integration of INTEGRATION.md: reference composer -> bbgpu_plonk_* resident prover
+//                                              -> reference Verifier; prints the proof in the `prove` format (GPU-linked builds only)
 //   plonk_xxx verify <num_gates> < proof       rebuild the same circuit's Verifier and check a proof given in the `prove` text
 //                                              format on stdin (used to verify proofs made by the native GPU prover)
 #include <barretenberg/curves/bn254/fq.hpp>
@@ -51,6 +53,17 @@
 #include <vector>
 
 using namespace barretenberg;
+
+// ---- the level-2 integration of INTEGRATION.md, made executable: the C ABI of libbbgpu.so (include/bbgpu.h), bound weakly so that the
+// all-CPU build (plonk_cpu, no GPU library on its link line) still links; `adapter` mode needs one of the GPU-linked builds
+extern "C" {
+#include "../include/bbgpu.h"
+}
+#pragma weak bbgpu_srs_register
+#pragma weak bbgpu_plonk_prover_create
+#pragma weak bbgpu_plonk_construct_proof
+#pragma weak bbgpu_plonk_prover_destroy
+#pragma weak bbgpu_last_error
 
 namespace {
 // the synthetic SRS secret (fixed, public: this is a test SRS)
@@ -322,6 +335,74 @@ int vk(size_t num_gates)
     return 0;
 }
 
+// What a barretenberg maintainer adds around Composer::preprocess() / Prover::construct_proof() to prove on the resident GPU prover:
+// the reference composer builds the circuit, its Prover state is handed to bbgpu_plonk_prover_create as it is, the proof comes back in
+// waffle::plonk_proof's own layout and the reference's own Verifier checks it.
+int adapter(size_t num_gates)
+{
+    if (!bbgpu_plonk_prover_create) {
+        fprintf(stderr, "adapter: this build is not linked against libbbgpu.so (use plonk_gpu / plonk_gpu_full)\n");
+        return 5;
+    }
+    std::unique_ptr<waffle::ComposerBase> composer = make_circuit(num_gates);
+    waffle::Prover prover = composer->preprocess();
+    waffle::Verifier verifier = waffle::preprocess(prover);
+    const waffle::ProverArithmeticWidget* w = dynamic_cast<const waffle::ProverArithmeticWidget*>(prover.widgets[0].get());
+    if (!w) return 3;
+    bbgpu_plonk_circuit c;
+    memset(&c, 0, sizeof c);
+    c.n = prover.n;
+    c.w_l = (const uint64_t*)prover.w_l.get_coefficients();
+    c.w_r = (const uint64_t*)prover.w_r.get_coefficients();
+    c.w_o = (const uint64_t*)prover.w_o.get_coefficients();
+    c.sigma_1_mapping = prover.sigma_1_mapping.data();
+    c.sigma_2_mapping = prover.sigma_2_mapping.data();
+    c.sigma_3_mapping = prover.sigma_3_mapping.data();
+    auto co = [](const barretenberg::polynomial& p) { return (const uint64_t*)const_cast<barretenberg::polynomial&>(p).get_coefficients(); };
+    c.q_m = co(w->q_m); c.q_l = co(w->q_l); c.q_r = co(w->q_r); c.q_o = co(w->q_o); c.q_c = co(w->q_c);
+    for (size_t i = 1; i < prover.widgets.size(); i++) {
+        if (auto* wb = dynamic_cast<const waffle::ProverBoolWidget*>(prover.widgets[i].get())) { c.q_bl = co(wb->q_bl); c.q_br = co(wb->q_br); c.q_bo = co(wb->q_bo); }
+        else if (auto* wm = dynamic_cast<const waffle::ProverMiMCWidget*>(prover.widgets[i].get())) { c.q_mimc_selector = co(wm->q_mimc_selector); c.q_mimc_coefficient = co(wm->q_mimc_coefficient); }
+        else if (auto* ws = dynamic_cast<const waffle::ProverSequentialWidget*>(prover.widgets[i].get())) c.q_o_next = co(ws->q_o_next);
+        else return 3;
+    }
+    const int srs = bbgpu_srs_register((const uint64_t*)prover.reference_string.monomials, prover.n);
+    const int h = srs >= 0 ? bbgpu_plonk_prover_create(&c, srs) : -1;
+    if (h < 0) {
+        fprintf(stderr, "adapter: %s\n", bbgpu_last_error ? bbgpu_last_error() : "bbgpu error");
+        return 6;
+    }
+    uint64_t words[BBGPU_PLONK_PROOF_WORDS];
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) { // the first call also prepares the circuit-only polynomials
+        auto t0 = std::chrono::steady_clock::now();
+        if (bbgpu_plonk_construct_proof(h, words) != 0) return 6;
+        best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    bbgpu_plonk_prover_destroy(h);
+    waffle::plonk_proof proof;
+    static_assert(sizeof(g1::affine_element) == 64 && sizeof(fr::field_t) == 32, "layout");
+    memcpy(&proof.W_L, words, 9 * 64);            // W_L, W_R, W_O, Z_1, T_LO, T_MID, T_HI, PI_Z, PI_Z_OMEGA (waffle_types.hpp:20-28)
+    memcpy(&proof.w_l_eval, words + 72, 12 * 32); // the twelve evaluations in declaration order (:30-43)
+    const bool ok = verifier.verify_proof(proof);
+    printf("n %zu\n", prover.n);
+    const g1::affine_element* pts[9] = { &proof.W_L, &proof.W_R, &proof.W_O, &proof.Z_1, &proof.T_LO, &proof.T_MID, &proof.T_HI, &proof.PI_Z, &proof.PI_Z_OMEGA };
+    const char* pn[9] = { "W_L", "W_R", "W_O", "Z_1", "T_LO", "T_MID", "T_HI", "PI_Z", "PI_Z_OMEGA" };
+    for (int i = 0; i < 9; i++) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "%s.x", pn[i]); hex4(nm, pts[i]->x.data);
+        snprintf(nm, sizeof nm, "%s.y", pn[i]); hex4(nm, pts[i]->y.data);
+    }
+    const fr::field_t* ev[7] = { &proof.w_l_eval, &proof.w_r_eval, &proof.w_o_eval, &proof.sigma_1_eval, &proof.sigma_2_eval, &proof.z_1_shifted_eval, &proof.linear_eval };
+    const char* en[7] = { "w_l_eval", "w_r_eval", "w_o_eval", "sigma_1_eval", "sigma_2_eval", "z_1_shifted_eval", "linear_eval" };
+    for (int i = 0; i < 7; i++) hex4(en[i], ev[i]->data);
+    if (c.q_mimc_selector || c.q_o_next) hex4("w_o_shifted_eval", proof.w_o_shifted_eval.data);
+    if (c.q_mimc_selector) hex4("q_mimc_coefficient_eval", proof.q_mimc_coefficient_eval.data);
+    printf("verified %d\n", ok ? 1 : 0);
+    fprintf(stderr, "construct_proof (resident GPU prover behind the reference composer) %.2f ms\n", best);
+    return ok ? 0 : 2;
+}
+
 bool rd4(const char* want, uint64_t* d)
 {
     char name[64], hex[80];
@@ -373,6 +454,7 @@ int main(int argc, char** argv)
     if (argc >= 3 && !strcmp(argv[1], "vk")) return vk((size_t)atol(argv[2]));
     if (argc >= 4 && !strcmp(argv[1], "dump")) return dump((size_t)atol(argv[2]), argv[3]);
     if (argc >= 3 && !strcmp(argv[1], "verify")) return verify((size_t)atol(argv[2]));
+    if (argc >= 3 && !strcmp(argv[1], "adapter")) return adapter((size_t)atol(argv[2]));
     fprintf(stderr, "usage: %s transcript <path> <num_points> | prove|trace|verify|vk <num_gates> | dump <num_gates> <path>\n", argv[0]);
     return 64;
 }

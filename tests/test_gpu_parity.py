@@ -477,3 +477,25 @@ def test_reference_prover_other_composers_on_gpu_bit_exact(golden, kind, gates):
     got = r.stdout.strip().split("\n")
     assert got == golden("plonk_trace.json")[kind]["proofs"][str(gates)]
     assert got[-1] == "verified 1"
+
+
+@pytest.mark.parametrize("kind,gates", [("standard", 65536), ("bool", 4096), ("mimc", 4094), ("extended", 160)])
+def test_reference_composer_to_resident_prover_adapter(golden, kind, gates):
+    """INTEGRATION.md level 2, executable (oracle/plonk_driver.cpp `adapter`): the reference's own composer builds the circuit, the Prover
+    state it assembles goes to bbgpu_plonk_prover_create unchanged (C++, the maintainer-side binding), the proof comes back in
+    waffle::plonk_proof's layout, equals the all-CPU reference prover's byte for byte, and the reference Verifier accepts it"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "plonk_gpu")
+    srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
+    if not (os.path.exists(exe) and os.path.exists(srs)):
+        pytest.skip("oracle/_ref/plonk_gpu not built (needs /root/reference at build time)")
+    env = dict(os.environ, OMP_NUM_THREADS="16")
+    if kind != "standard":
+        env["BB_CIRCUIT"] = kind
+    r = subprocess.run([exe, "adapter", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    got = r.stdout.strip().split("\n")
+    want = golden("plonk_proofs.json")["proofs"][str(gates)] if kind == "standard" else golden("plonk_trace.json")[kind]["proofs"][str(gates)]
+    assert got == want
