@@ -36,6 +36,14 @@
 namespace bbgpu {
 
 using Fr = FrP;
+// Wave priority of the digit / sort kernels.  In the two-deep pipeline they run beside the PREVIOUS MSM's accumulation, stretched from
+// 0.23 ms to ~1.07 ms, and end a few tens of microseconds after it -- the next accumulation waits for them.  Priority 2 (above the
+// accumulation's 0, below the tail kernels' 3) lets them finish in time: measured 1.400 -> 1.382 ms/step at 2^20 and 0.318 -> 0.305 ms
+// for the 2-window share of an 8-way split (tools/msm_ab.py, A/B in one box; priority 3 is no better).
+#ifndef BBGPU_FRONT_PRIO
+#define BBGPU_FRONT_PRIO 2
+#endif
+#define FRONT_PRIO() __builtin_amdgcn_s_setprio(BBGPU_FRONT_PRIO)
 constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
 constexpr int MSM_MAX_C = 16;    // digits stored as int16, LDS histogram of 2^15 counters
 constexpr int MSM_THREADS = 256;
@@ -263,6 +271,7 @@ struct ScalarSets {
 __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, int16_t* __restrict__ digits_all,
                                                                uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we)
 {
+    FRONT_PRIO();
     // only windows [wb, we) are stored (a rank of a window-sharded MSM needs its share only); the carry chain still starts at window 0
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -308,6 +317,7 @@ __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(3
                                                                 uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0,
                                                                 uint32_t wpg)
 {
+    FRONT_PRIO();
     __shared__ uint32_t lh[SORT_THREADS];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
     lh[threadIdx.x] = 0;
@@ -330,6 +340,7 @@ __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(3
 __global__ void __launch_bounds__(SORT_THREADS) sortA_colscan_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ bintot, uint32_t bins,
                                                                    uint32_t slices)
 {
+    FRONT_PRIO();
     const uint32_t wl = blockIdx.y, lane = threadIdx.x & 63;
     const uint32_t bin = blockIdx.x * (SORT_THREADS / 64) + (threadIdx.x >> 6);
     if (bin >= bins) return; // whole waves exit together
@@ -356,6 +367,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sortA_colscan_kernel(uint32_t* _
 __global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(const uint32_t* __restrict__ bintot, uint32_t* __restrict__ binstart,
                                                                 uint32_t* __restrict__ totals, uint32_t bins)
 {
+    FRONT_PRIO();
     __shared__ uint32_t part[SORT_THREADS];
     const uint32_t wl = blockIdx.x, t = threadIdx.x;
     const uint32_t mine = t < bins ? bintot[(size_t)wl * bins + t] : 0;
@@ -373,6 +385,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(const uint32_t
 // window bases (exclusive prefix of the window totals), M = total number of entries -> gstart[total_buckets]
 __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t nw)
 {
+    FRONT_PRIO();
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t run = 0;
         for (uint32_t w = 0; w < nw; w++) {
@@ -390,6 +403,7 @@ __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(3
                                                                    uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
                                                                    uint32_t idx_stride, uint32_t windows_per_job)
 {
+    FRONT_PRIO();
     __shared__ uint32_t lc[SORT_THREADS];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
     if (threadIdx.x < bins)
@@ -417,6 +431,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sortB_kernel(const uint32_t* __r
                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ sorted, uint32_t* __restrict__ gstart,
                                                    uint32_t bins, uint32_t lb, uint32_t nb)
 {
+    FRONT_PRIO();
     __shared__ uint32_t cnt[128];
     __shared__ uint32_t cur[128];
     const uint32_t bin = blockIdx.x, wl = blockIdx.y, t = threadIdx.x;
