@@ -20,7 +20,8 @@ void ntt_release_tables();
 namespace host { struct Xyzz; }
 struct MsmTiming {
     int count = 0;
-    float ms[8]; // [0] total device time, then digits, sort, accumulate kernel, merge, row/col folds, slices+collect
+    float ms[8]; // [0] total device time, then digits, sort, accumulate kernel, merge, row/col folds, slices+collect,
+                 // [7] accumulate kernel without the time it sat queued behind the previous MSM's accumulation (two MSMs in flight)
 };
 struct MsmWorkspace {
     uint8_t* base = nullptr;
@@ -38,6 +39,7 @@ struct MsmSlot {
     bool pending = false, trivial = false, timed = false;
     size_t n = 0;
     uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0, jobs = 1;
+    uint64_t acc_seq = 0; // position of this MSM's accumulation in the process-wide sequence of timed accumulations (0 = none)
     void release();
 };
 int msm_choose_c(size_t n);

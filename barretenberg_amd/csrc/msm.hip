@@ -884,6 +884,21 @@ int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t t
 // commitments per round, prover.cpp:65-122,650-658): each job is a bucket set ("group") of the shared sort / accumulate / merge /
 // reduction kernels, so the batch costs one chain of launches and one chain of dependent group additions instead of `jobs`.
 // Table mode and the full window range only.  msm_finish_batch returns one point per job.
+// "accumulation ended" events of the last ACC_RING timed MSMs, in issue order.  With two MSMs in flight the next accumulation is
+// enqueued while the previous one still runs (its sort is done early), so the event pair around the kernel also measures the time it sat
+// in the queue; the kernel cannot execute before the previous accumulation has drained (one resident wave of workgroups fills the chip),
+// so its execution time is at most the spacing of consecutive "ended" events.
+constexpr int ACC_RING = 8;
+static hipEvent_t g_acc_end[ACC_RING];
+static uint64_t g_acc_seq = 0; // number of timed accumulations issued so far
+static int acc_ring_record(MsmSlot& S, hipStream_t st)
+{
+    if (g_acc_seq == 0)
+        for (int i = 0; i < ACC_RING; i++) HIPCHK(hipEventCreate(&g_acc_end[i]));
+    S.acc_seq = ++g_acc_seq;
+    HIPCHK(hipEventRecord(g_acc_end[S.acc_seq % ACC_RING], st));
+    return BBGPU_OK;
+}
 int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
                     size_t n, int wb, int we, hipStream_t st, bool want_timing)
 {
@@ -980,7 +995,12 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     const uint32_t merge_light = std::max(6u, 8u << logG);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
     msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch, acc_prio());
-    if (tm) HIPCHK(hipEventRecord(ev[3], st));
+    if (tm) {
+        HIPCHK(hipEventRecord(ev[3], st));
+        if (int rc = acc_ring_record(S, st)) return rc;
+    } else {
+        S.acc_seq = 0;
+    }
     HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
     msm_merge_kernel<<<(uint32_t)((((uint64_t)total_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
                                                                                                                      total_buckets, ch, merge_light, logG);
@@ -1035,6 +1055,13 @@ static int finish_timing(MsmSlot& S, MsmTiming* timing)
             HIPCHK(hipEventElapsedTime(&ms, S.ev[i], S.ev[i + 1]));
             timing->ms[timing->count++] = ms;
         }
+        float exec = timing->ms[3];
+        // previous timed accumulation still in the ring (not overwritten by a later issue) and already finished (it precedes this one)
+        if (S.acc_seq > 1 && g_acc_seq - (S.acc_seq - 1) < (uint64_t)ACC_RING &&
+            hipEventElapsedTime(&ms, g_acc_end[(S.acc_seq - 1) % ACC_RING], g_acc_end[S.acc_seq % ACC_RING]) == hipSuccess && ms > 0.0f && ms < exec)
+            exec = ms;
+        (void)hipGetLastError();
+        timing->ms[timing->count++] = exec;
     }
     return BBGPU_OK;
 }

@@ -208,7 +208,8 @@ int bbgpu_plonk_challenges_from_proof(const uint64_t proof[BBGPU_PLONK_PROOF_WOR
 
 /* ---- instrumentation (bench.py) ---------------------------------------------------------------------------------
  * Device time in milliseconds of the kernels launched by the most recent bbgpu_*_device call on this thread, measured
- * with hipEvents on the stream the kernels ran on.  index: 0 = total, then per stage. */
+ * with hipEvents on the stream the kernels ran on.  index: 0 = total, then per stage: 1 digits, 2 sort, 3 accumulation,
+ * 4 merge, 5 row/column sums, 6 final sums, 7 accumulation without the time it sat queued behind the previous MSM's accumulation. */
 int bbgpu_last_timing(float* ms_out, int max_entries);
 void bbgpu_set_timing(int enabled);
 
