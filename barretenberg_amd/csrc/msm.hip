@@ -515,11 +515,14 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint3
     set_infinity(acc);
     // software pipeline: the gather of entry e+1 (index, then 64 bytes of point, possibly from HBM when the window
     // tables exceed the Infinity Cache) is in flight while the ~2,300 VALU instructions of the mixed addition of entry e run
+    // The INDEX runs two entries ahead: the gather address of entry e+1 is then known when iteration e starts, instead of costing an
+    // index-load latency before the gather can even be issued.
     uint32_t v = sorted[p0];
+    uint32_t vn = sorted[min(p0 + 1, p1 - 1)];
     uint32_t w[16];
     ld16(srs + (size_t)(v & 0x7fffffffu) * 16, w);
     for (uint32_t e = p0; e < p1; e++) {
-        const uint32_t vn = sorted[min(e + 1, p1 - 1)];
+        const uint32_t vnn = sorted[min(e + 2, p1 - 1)];
         uint32_t wn[16];
         ld16(srs + (size_t)(vn & 0x7fffffffu) * 16, wn);
         if (e == next_end) {
@@ -531,6 +534,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint3
         load_affine_m261(p, w);
         madd(acc, cond_neg_affine(p, (v >> 31) != 0));
         v = vn;
+        vn = vnn;
 #pragma unroll
         for (int i = 0; i < 16; i++) w[i] = wn[i];
     }
