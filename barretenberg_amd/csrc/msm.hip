@@ -45,7 +45,8 @@ using Fr = FrP;
 #endif
 #define FRONT_PRIO() __builtin_amdgcn_s_setprio(BBGPU_FRONT_PRIO)
 constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
-constexpr int MSM_MAX_C = 16;    // digits stored as int16, LDS histogram of 2^15 counters
+constexpr int MSM_MAX_C = 16;    // largest window without tables (one bucket set per window); digits stored as int16
+constexpr int MSM_MAX_TABLE_C = 17; // with tables (one shared bucket set): 17-bit windows -> 15 of them, digits stored as int32
 constexpr int MSM_THREADS = 256;
 constexpr int MSM_MAX_JOBS = 4;  // MSMs over the same points issued as one batch (one bucket set each)
 
@@ -268,7 +269,7 @@ __global__ void srs_gen_points_kernel(const uint32_t* __restrict__ tab, Limbs9 x
 struct ScalarSets {
     const uint32_t* p[MSM_MAX_JOBS]; // one scalar vector per job of a batch (blockIdx.y)
 };
-__global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, int16_t* __restrict__ digits_all,
+template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, DT* __restrict__ digits_all,
                                                                uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we)
 {
     FRONT_PRIO();
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* __restrict__ scalars = sets.p[blockIdx.y];
-    int16_t* __restrict__ digits = digits_all + (size_t)blockIdx.y * num_windows * n;
+    DT* __restrict__ digits = digits_all + (size_t)blockIdx.y * num_windows * n;
     uint32_t w[8], k[9];
     ld8(scalars + (size_t)i * 8, w);
     to_canonical(mul(unpack<Fr>(w), fe_from<Fr>(Fr::M256_TO_PLAIN)), w); // x*2^256 * 2^5 / 2^261 = x, canonical
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets
         v = (v & mask) + carry;
         carry = (win + 1 < num_windows && v >= half) ? 1u : 0u;
         const int32_t d = (int32_t)v - (int32_t)(carry << sz);
-        if (win >= wb) digits[(size_t)win * n + i] = (int16_t)d;
+        if (win >= wb) digits[(size_t)win * n + i] = (DT)d;
     }
 }
 
@@ -313,7 +314,7 @@ constexpr uint32_t SORT_MAX_LB = 7;
 
 // A "group" is a set of `wpg` consecutive windows that share one bucket set: 1 window per group normally, all windows of
 // the call in one group when the SRS carries pre-shifted window tables (the window weight is then baked into the point).
-__global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const int16_t* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
+template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const DT* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
                                                                 uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0,
                                                                 uint32_t wpg)
 {
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(3
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
     for (uint32_t k = 0; k < wpg; k++) {
-        const int16_t* dg = digits + (size_t)(win0 + wl * wpg + k) * n;
+        const DT* dg = digits + (size_t)(win0 + wl * wpg + k) * n;
         for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
             const int d = dg[i];
             if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
@@ -397,7 +398,7 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
     }
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const int16_t* __restrict__ digits, const uint32_t* __restrict__ cursorsA,
+template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const DT* __restrict__ digits, const uint32_t* __restrict__ cursorsA,
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                    uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
                                                                    uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(3
     const uint32_t lomask = (1u << lb) - 1;
     for (uint32_t k = 0; k < wpg; k++) {
         const uint32_t wabs = win0 + wl * wpg + k;
-        const int16_t* dg = digits + (size_t)wabs * n;
+        const DT* dg = digits + (size_t)wabs * n;
         const uint32_t row = (wabs % windows_per_job) * idx_stride; // row of the pre-shifted table (0 without tables); batches repeat the windows per job
         for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
             const int d = dg[i];
@@ -834,7 +835,7 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     MsmPlan P = make_plan(n, c);
     size_t tot = 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * n * 2); // digits (a batch of j jobs passes nw = j * W)
+    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * n * (c > 16 ? 4 : 2)); // digits (a batch of j jobs passes nw = j * W)
     tot += al((size_t)nw * P.slices * 1024 * 4);             // pass-A histogram / cursors (<= 1024 bins)
     tot += al((size_t)nw * 1024 * 4 + 256);                  // bin starts
     tot += al((size_t)nw * 1024 * 4 + 256);                  // bin totals
@@ -949,7 +950,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     uint8_t* p = ws.base;
-    int16_t* digits = (int16_t*)p; p += al((size_t)std::max<size_t>(P.W, nw) * n * 2);
+    void* digits = (void*)p; p += al((size_t)std::max<size_t>(P.W, nw) * n * (c > 16 ? 4 : 2));
     uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * 1024 * 4);
     uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
     uint32_t* bintot = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
@@ -976,14 +977,19 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     // K0
     ScalarSets sets{};
     for (int j = 0; j < jobs; j++) sets.p[j] = (const uint32_t*)d_scalars_v[j];
-    msm_digits_kernel<<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, digits, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
+    const bool wide = c > 16; // 17-bit windows: signed digits up to +-2^16
+    if (wide) msm_digits_kernel<int32_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int32_t*)digits, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
+    else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
-    sortA_hist_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
+    if (wide) sortA_hist_kernel<int32_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int32_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
+    else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
     sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
     sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
     sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
-    sortA_scatter_kernel<<<dim3(slices, G), SORT_THREADS, 0, st>>>(digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
+    if (wide) sortA_scatter_kernel<int32_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int32_t*)digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
+                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W);
+    else sortA_scatter_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
                                                                    slice_len, (uint32_t)wb, wpg, idx_stride, P.W);
     sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     if (tm) HIPCHK(hipEventRecord(ev[2], st));

@@ -308,7 +308,7 @@ def main():
             "dtype": "u32x9 (256-bit Montgomery, 29-bit limbs)",
             "data": "synthetic",
             "config": {"workload": "2^%d-point BN254 G1 MSM, uniformly random 253-bit scalars vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
-                       "parallelism": "digit windows [%d) sharded over %d rank(s), one all-gather of 96 B partial sums" % (W, world) if world > 1 else "single GPU, %d windows of 16 bits" % W,
+                       "parallelism": "digit windows [%d) sharded over %d rank(s), one all-gather of 96 B partial sums" % (W, world) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
                        "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
                          "merge": float(stage[4]), "bucket_folds": float(stage[5]), "slices_collect": float(stage[6]),
