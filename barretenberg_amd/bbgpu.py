@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
     "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
     "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_msm_g1",
-    "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_wait",
+    "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing",
     "bbgpu_set_timing",
@@ -97,6 +97,8 @@ class BbGpu:
         L.bbgpu_srs_num_windows.argtypes = [C.c_int, C.c_size_t]
         L.bbgpu_msm_g1_device.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
         L.bbgpu_msm_g1_device_async.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.bbgpu_msm_g1_device_rows_async.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.bbgpu_srs_has_window_tables.argtypes = [C.c_int]
         L.bbgpu_msm_g1_wait.argtypes = [C.c_int, u64p]
         L.bbgpu_msm_g1_device_batch_async.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p]
         L.bbgpu_msm_g1_batch_wait.argtypes = [C.c_int, u64p]
@@ -251,6 +253,15 @@ class BbGpu:
             window_end = self.srs_num_windows(handle, n)
         return self._chk(self.lib.bbgpu_msm_g1_device_async(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,
                                                            C.c_void_p(stream or 0)))
+
+    def msm_device_rows_async(self, handle, d_scalars_ptr, n, row_begin, row_end, offset=0, stream=None):
+        """share [row_begin, row_end) of the W * n (window, point) pairs, window-major (row = w * n + i): a split that need not follow
+        window boundaries (needs the window tables); returns a ticket for msm_wait()"""
+        return self._chk(self.lib.bbgpu_msm_g1_device_rows_async(handle, offset, C.c_void_p(d_scalars_ptr), n, row_begin, row_end,
+                                                                C.c_void_p(stream or 0)))
+
+    def srs_has_window_tables(self, handle):
+        return self._chk(self.lib.bbgpu_srs_has_window_tables(handle)) == 1
 
     def msm_wait(self, ticket):
         out = np.zeros(12, dtype=np.uint64)

@@ -47,7 +47,9 @@ int msm_num_windows(int c);
 int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
               int we, hipStream_t st, bool want_timing);
 int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
-                    size_t n, int wb, int we, hipStream_t st, bool want_timing);
+                    size_t n, int wb, int we, hipStream_t st, bool want_timing, uint32_t row_i0 = 0, uint32_t row_i1 = 0xffffffffu);
+int msm_issue_rows(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n,
+                   uint64_t row_begin, uint64_t row_end, hipStream_t st, bool want_timing);
 int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing);
 int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uint32_t** d_tab_out, hipStream_t st);
 int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);

@@ -316,7 +316,7 @@ constexpr uint32_t SORT_MAX_LB = 7;
 // the call in one group when the SRS carries pre-shifted window tables (the window weight is then baked into the point).
 template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const DT* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
                                                                 uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0,
-                                                                uint32_t wpg)
+                                                                uint32_t wpg, uint32_t first_i0, uint32_t last_i1)
 {
     FRONT_PRIO();
     __shared__ uint32_t lh[SORT_THREADS];
@@ -326,7 +326,9 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
     for (uint32_t k = 0; k < wpg; k++) {
         const DT* dg = digits + (size_t)(win0 + wl * wpg + k) * n;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        // a row-range share (msm_issue_rows) owns only points >= first_i0 of its first window and < last_i1 of its last one
+        const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
+        for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
             const int d = dg[i];
             if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
         }
@@ -402,7 +404,7 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                    uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
                                                                    uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
-                                                                   uint32_t idx_stride, uint32_t windows_per_job)
+                                                                   uint32_t idx_stride, uint32_t windows_per_job, uint32_t first_i0, uint32_t last_i1)
 {
     FRONT_PRIO();
     __shared__ uint32_t lc[SORT_THREADS];
@@ -416,7 +418,8 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
         const uint32_t wabs = win0 + wl * wpg + k;
         const DT* dg = digits + (size_t)wabs * n;
         const uint32_t row = (wabs % windows_per_job) * idx_stride; // row of the pre-shifted table (0 without tables); batches repeat the windows per job
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
+        for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
             const int d = dg[i];
             if (d) {
                 const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
@@ -882,7 +885,18 @@ void MsmWorkspace::release()
 int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
               int we, hipStream_t st, bool want_timing)
 {
-    return msm_issue_batch(S, d_srs, d_tab, tab_stride, tab_c, &d_scalars, 1, n, wb, we, st, want_timing);
+    return msm_issue_batch(S, d_srs, d_tab, tab_stride, tab_c, &d_scalars, 1, n, wb, we, st, want_timing, 0, (uint32_t)n);
+}
+// Share [row_begin, row_end) of the W * n (window, point) pairs, rows counted window-major: row = w * n + i.  With window tables every pair
+// is just one table row feeding the one shared bucket set, so ANY split of the rows is a valid split of the MSM; splitting rows instead
+// of whole windows keeps N ranks balanced when N does not divide W (15 windows over 8 ranks: 1.875 windows each instead of 2).
+int msm_issue_rows(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n,
+                   uint64_t row_begin, uint64_t row_end, hipStream_t st, bool want_timing)
+{
+    if (!d_tab || n == 0 || row_end <= row_begin || row_end > (uint64_t)msm_num_windows(tab_c) * n) return BBGPU_ERR_ARG;
+    const int wb = (int)(row_begin / n), we = (int)((row_end + n - 1) / n);
+    const uint32_t i0 = (uint32_t)(row_begin - (uint64_t)wb * n), i1 = (uint32_t)(row_end - (uint64_t)(we - 1) * n);
+    return msm_issue_batch(S, d_srs, d_tab, tab_stride, tab_c, &d_scalars, 1, n, wb, we, st, want_timing, i0, i1);
 }
 
 // `jobs` MSMs of n scalars each over the SAME points as one pass through the pipeline (the prover's 3 / 1 / 3 / 2
@@ -905,7 +919,7 @@ static int acc_ring_record(MsmSlot& S, hipStream_t st)
     return BBGPU_OK;
 }
 int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
-                    size_t n, int wb, int we, hipStream_t st, bool want_timing)
+                    size_t n, int wb, int we, hipStream_t st, bool want_timing, uint32_t row_i0, uint32_t row_i1)
 {
     MsmWorkspace& ws = S.ws;
     S.jobs = (uint32_t)jobs;
@@ -922,6 +936,9 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     const int c = table ? tab_c : msm_choose_c(n);
     const MsmPlan P = make_plan(n, c);
     if (wb < 0 || we > (int)P.W || wb >= we) return BBGPU_ERR_ARG;
+    if (row_i1 > n) row_i1 = (uint32_t)n;
+    // a share that starts / ends inside a window (msm_issue_rows): only with one shared bucket set, i.e. against window tables
+    if ((row_i0 != 0 || row_i1 != n) && (!table || jobs != 1 || row_i0 >= n || (we - wb == 1 && row_i0 >= row_i1))) return BBGPU_ERR_ARG;
     if (jobs < 1 || jobs > MSM_MAX_JOBS || (jobs > 1 && (!table || wb != 0 || we != (int)P.W))) {
         set_error("batched MSM: 1..%d jobs, window tables and the full window range required", MSM_MAX_JOBS);
         return BBGPU_ERR_ARG;
@@ -982,15 +999,15 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
-    if (wide) sortA_hist_kernel<int32_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int32_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
-    else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg);
+    if (wide) sortA_hist_kernel<int32_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int32_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
+    else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
     sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
     sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
     sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
     if (wide) sortA_scatter_kernel<int32_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int32_t*)digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
-                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W);
+                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
     else sortA_scatter_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
-                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W);
+                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
     sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     if (tm) HIPCHK(hipEventRecord(ev[2], st));
     // K4 + K4m

@@ -175,7 +175,14 @@ def main():
     wb, we = W * rank // world, W * (rank + 1) // world
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the 96-byte partial sums are exchanged
 
+    # with window tables (one shared bucket set) the W * n (window, point) pairs split at ANY row, so every rank takes exactly 1/N of them
+    # even when N does not divide W (15 windows of 17 bits at 2^20); without tables the split follows whole windows
+    by_rows = world > 1 and G.srs_has_window_tables(srs)
+    rows = (W * n * rank // world, W * n * (rank + 1) // world)
+
     def issue():
+        if by_rows:
+            return G.msm_device_rows_async(srs, d_scalars.data_ptr(), n, rows[0], rows[1])
         return G.msm_device_async(srs, d_scalars.data_ptr(), n, 0, wb, we) if we > wb else None
 
     stage_log = []  # per-MSM stage times (HIP events on the stream the kernels ran on), filled while timing is on
@@ -293,6 +300,7 @@ def main():
             except Exception:
                 traffic = None
         ntt_bytes = 2 * 32 * n
+        share_adds = (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation
         line = {
             "metric": "BN254 G1 MSM points/sec at n=2^%d (Fr NTT elems/sec in 'ntt')" % args.log2n,
             "value": n / (msm_ms * 1e-3),
@@ -308,7 +316,7 @@ def main():
             "dtype": "u32x9 (256-bit Montgomery, 29-bit limbs)",
             "data": "synthetic",
             "config": {"workload": "2^%d-point BN254 G1 MSM, uniformly random 253-bit scalars vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
-                       "parallelism": "digit windows [%d) sharded over %d rank(s), one all-gather of 96 B partial sums" % (W, world) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
+                       "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
                        "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
                          "merge": float(stage[4]), "bucket_folds": float(stage[5]), "slices_collect": float(stage[6]),
@@ -322,9 +330,9 @@ def main():
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes,
                          # the bound that does apply: one mixed XYZZ addition per (point, window) = 1,467 v_mad_u64_u32 per lane,
                          # against the chip's measured issue rate for that instruction (470 G wave-instructions/s)
-                         "valu": {"bound": "v_mad_u64_u32 issue", "achieved": n * (we - wb) * 1467 / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0,
+                         "valu": {"bound": "v_mad_u64_u32 issue", "achieved": share_adds * 1467 / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0,
                                   "peak": 470e9 * 64 / 1e12, "unit": "T lane-mad/s",
-                                  "frac": (n * (we - wb) * 1467 / (acc_ms * 1e-3)) / (470e9 * 64) if acc_ms > 0 else 0.0}},
+                                  "frac": (share_adds * 1467 / (acc_ms * 1e-3)) / (470e9 * 64) if acc_ms > 0 else 0.0}},
             "ntt": {"metric": "Fr radix-2 NTT elements/s at n=2^%d, in place on a device-resident vector" % args.log2n,
                     "fft": ntt["fft"], "coset_fft": ntt["coset_fft"],
                     "roofline": {"bound": "hbm", "achieved": ntt_bytes / (ntt["fft"]["device_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

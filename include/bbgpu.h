@@ -116,6 +116,14 @@ int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars
  * on its own internal stream. */
 int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                               int window_end, void* hip_stream);
+/* The same with a share that may start and end INSIDE a digit window: rows [row_begin, row_end) of the W x n (window, point) pairs counted
+ * window-major, row = w * n + i, 0 <= row_begin < row_end <= W * n with W = bbgpu_srs_num_windows().  Against window tables every pair is
+ * one table row feeding the one shared bucket set, so any split of the rows splits the MSM; N ranks taking [W n r / N, W n (r + 1) / N)
+ * stay balanced when N does not divide W.  Needs the window tables (bbgpu_srs_has_window_tables() == 1), else BBGPU_ERR_STATE.
+ * Collected with bbgpu_msm_g1_wait like any other ticket; the partial sums of a complete split add up to the MSM (bbgpu_g1_sum). */
+int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, uint64_t row_begin, uint64_t row_end,
+                                   void* hip_stream);
+int bbgpu_srs_has_window_tables(int srs_handle); /* 1 / 0, < 0: unknown handle */
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12]);
 /* Whole-batch entry (the prover commits 3 / 1 / 3 / 2 polynomials per round over the same SRS,
  * prover.cpp:65-122,650-658): `jobs` (1..4) resident scalar vectors of n scalars each against points [offset, offset + n) of a

@@ -431,6 +431,33 @@ def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
     assert np.array_equal(out, out2)
 
 
+def test_msm_row_range_shares_add_up(gpu, oracle, msm_small):
+    """bbgpu_msm_g1_device_rows_async: shares of the W * n (window, point) pairs that start and end INSIDE digit windows (what bench.py
+    gives N ranks when N does not divide W) add up to the MSM for N = 2, 3, 7, 8 and for ragged cuts; refused without window tables"""
+    import torch
+    from barretenberg_amd import BbGpuError
+    g, srs, table, scalars = msm_small
+    n = 1 << 14
+    h = gpu.srs_register(table)
+    d = torch.from_numpy(scalars[:n].view(np.int64)).cuda()
+    if not gpu.srs_has_window_tables(h):
+        with pytest.raises(BbGpuError):
+            gpu.msm_device_rows_async(h, d.data_ptr(), n, 0, n)
+        return
+    want = oracle.msm_affine(scalars, table, n)
+    W = gpu.srs_num_windows(h, n)
+    R = W * n
+    for cuts in ([0, R // 2, R], [0, R // 3, 2 * R // 3, R], [R * r // 7 for r in range(8)], [R * r // 8 for r in range(9)],
+                 [0, 1, n - 1, n, n + 1, 5 * n + 17, R - 1, R]):
+        parts = [gpu.msm_wait(gpu.msm_device_rows_async(h, d.data_ptr(), n, a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
+        total = gpu.g1_sum(np.stack(parts))
+        assert np.array_equal(total[:8], want[:8]), cuts
+    with pytest.raises(BbGpuError):
+        gpu.msm_device_rows_async(h, d.data_ptr(), n, 5, 5)
+    with pytest.raises(BbGpuError):
+        gpu.msm_device_rows_async(h, d.data_ptr(), n, 0, R + 1)
+
+
 # ------------------------------------------------------------------ config 5: the reference prover on the GPU ----------
 @pytest.mark.parametrize("build", ["plonk_gpu", "plonk_gpu_full"])
 @pytest.mark.parametrize("gates", [32, 1024, 16384, 65536])

@@ -17,12 +17,12 @@ d = torch.from_numpy(sc.view(np.int64)).cuda()
 W = G.srs_num_windows(srs, n)
 base = None
 for N in (1, 2, 4, 8):
-    we = W // N
+    rows = W * n // N  # bench.py gives every rank W n / N table rows (a share need not end at a window boundary)
     for depth in (1, 2, 3, 4):
         def run(k):
             infl = []
             for _ in range(k):
-                infl.append(G.msm_device_async(srs, d.data_ptr(), n, 0, 0, we))
+                infl.append(G.msm_device_rows_async(srs, d.data_ptr(), n, 0, rows))
                 if len(infl) == depth:
                     G.msm_wait(infl.pop(0))
             while infl:
@@ -32,14 +32,14 @@ for N in (1, 2, 4, 8):
         t0 = time.perf_counter(); run(24); dt = (time.perf_counter() - t0) / 24
         if base is None and depth == 2:
             base = dt
-        print("N=%d (%2d windows per rank), %d in flight: %.3f ms/step%s" % (N, we, depth, dt * 1e3, "  = %.2fx of N=1" % (base / dt) if base else ""), flush=True)
+        print("N=%d (%.3f windows per rank), %d in flight: %.3f ms/step%s" % (N, W / N, depth, dt * 1e3, "  = %.2fx of N=1" % (base / dt) if base else ""), flush=True)
 
 # host-side cost of one step at the smallest share: time inside the two calls
-we = W // 8
+rows8 = W * n // 8
 ti = tw = 0.0
 infl = []
 for _ in range(40):
-    t0 = time.perf_counter(); infl.append(G.msm_device_async(srs, d.data_ptr(), n, 0, 0, we)); ti += time.perf_counter() - t0
+    t0 = time.perf_counter(); infl.append(G.msm_device_rows_async(srs, d.data_ptr(), n, 0, rows8)); ti += time.perf_counter() - t0
     if len(infl) == 2:
         t0 = time.perf_counter(); G.msm_wait(infl.pop(0)); tw += time.perf_counter() - t0
 while infl:
