@@ -46,7 +46,7 @@ using Fr = FrP;
 #define FRONT_PRIO() __builtin_amdgcn_s_setprio(BBGPU_FRONT_PRIO)
 constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
 constexpr int MSM_MAX_C = 16;    // largest window without tables (one bucket set per window); digits stored as int16
-constexpr int MSM_MAX_TABLE_C = 17; // with tables (one shared bucket set): 17-bit windows -> 15 of them, digits stored as int32
+constexpr int MSM_MAX_TABLE_C = 17; // with tables (one shared bucket set): 17-bit windows -> 15 of them, digits stored as uint16 magnitude + sign bit
 constexpr int MSM_THREADS = 256;
 constexpr int MSM_MAX_JOBS = 4;  // MSMs over the same points issued as one batch (one bucket set each)
 
@@ -269,7 +269,21 @@ __global__ void srs_gen_points_kernel(const uint32_t* __restrict__ tab, Limbs9 x
 struct ScalarSets {
     const uint32_t* p[MSM_MAX_JOBS]; // one scalar vector per job of a batch (blockIdx.y)
 };
-template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, DT* __restrict__ digits_all,
+// Digit storage: int16 for windows of up to 16 bits.  17-bit windows give digits in [-2^16, 2^16): stored as a uint16 magnitude
+// (d >= 0: d, d < 0: -d - 1) plus one sign bit per digit, packed 64 to a word by a wave ballot -- 2.03 bytes per digit instead of the
+// 4 of an int32 array, which the histogram and the scatter pass both read in full.
+template <class DT> struct DigitTraits { static constexpr bool wide = false; };
+template <> struct DigitTraits<uint16_t> { static constexpr bool wide = true; };
+template <class DT> __device__ __forceinline__ int load_digit(const DT* __restrict__ dg, const unsigned long long* __restrict__ sg, uint32_t i)
+{
+    if constexpr (DigitTraits<DT>::wide) {
+        const int u = dg[i];
+        return ((sg[i >> 6] >> (i & 63u)) & 1ull) ? -u - 1 : u;
+    } else {
+        return dg[i];
+    }
+}
+template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, DT* __restrict__ digits_all, unsigned long long* __restrict__ signs_all,
                                                                uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we)
 {
     FRONT_PRIO();
@@ -278,6 +292,8 @@ template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_ke
     if (i >= n) return;
     const uint32_t* __restrict__ scalars = sets.p[blockIdx.y];
     DT* __restrict__ digits = digits_all + (size_t)blockIdx.y * num_windows * n;
+    const uint32_t s64 = (n + 63) >> 6; // sign words per window (a wave covers 64 consecutive scalars: blockDim is a multiple of 64)
+    unsigned long long* __restrict__ signs = signs_all + (size_t)blockIdx.y * num_windows * s64;
     uint32_t w[8], k[9];
     ld8(scalars + (size_t)i * 8, w);
     to_canonical(mul(unpack<Fr>(w), fe_from<Fr>(Fr::M256_TO_PLAIN)), w); // x*2^256 * 2^5 / 2^261 = x, canonical
@@ -296,7 +312,15 @@ template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_ke
         v = (v & mask) + carry;
         carry = (win + 1 < num_windows && v >= half) ? 1u : 0u;
         const int32_t d = (int32_t)v - (int32_t)(carry << sz);
-        if (win >= wb) digits[(size_t)win * n + i] = (DT)d;
+        if (win >= wb) {
+            if constexpr (DigitTraits<DT>::wide) {
+                const unsigned long long neg = __ballot(d < 0);
+                digits[(size_t)win * n + i] = (DT)(d < 0 ? -d - 1 : d);
+                if ((threadIdx.x & 63u) == 0) signs[(size_t)win * s64 + (i >> 6)] = neg;
+            } else {
+                digits[(size_t)win * n + i] = (DT)d;
+            }
+        }
     }
 }
 
@@ -314,7 +338,7 @@ constexpr uint32_t SORT_MAX_LB = 7;
 
 // A "group" is a set of `wpg` consecutive windows that share one bucket set: 1 window per group normally, all windows of
 // the call in one group when the SRS carries pre-shifted window tables (the window weight is then baked into the point).
-template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const DT* __restrict__ digits, uint32_t* __restrict__ histA, uint32_t n,
+template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, uint32_t* __restrict__ histA, uint32_t n,
                                                                 uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0,
                                                                 uint32_t wpg, uint32_t first_i0, uint32_t last_i1)
 {
@@ -326,10 +350,11 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
     for (uint32_t k = 0; k < wpg; k++) {
         const DT* dg = digits + (size_t)(win0 + wl * wpg + k) * n;
+        const unsigned long long* sg = signs + (size_t)(win0 + wl * wpg + k) * ((n + 63) >> 6);
         // a row-range share (msm_issue_rows) owns only points >= first_i0 of its first window and < last_i1 of its last one
         const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
         for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
-            const int d = dg[i];
+            const int d = load_digit<DT>(dg, sg, i);
             if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
         }
     }
@@ -400,7 +425,7 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
     }
 }
 
-template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const DT* __restrict__ digits, const uint32_t* __restrict__ cursorsA,
+template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, const uint32_t* __restrict__ cursorsA,
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                    uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
                                                                    uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
@@ -417,10 +442,11 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
     for (uint32_t k = 0; k < wpg; k++) {
         const uint32_t wabs = win0 + wl * wpg + k;
         const DT* dg = digits + (size_t)wabs * n;
+        const unsigned long long* sg = signs + (size_t)wabs * ((n + 63) >> 6);
         const uint32_t row = (wabs % windows_per_job) * idx_stride; // row of the pre-shifted table (0 without tables); batches repeat the windows per job
         const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
         for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
-            const int d = dg[i];
+            const int d = load_digit<DT>(dg, sg, i);
             if (d) {
                 const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
                 const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
@@ -838,7 +864,8 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
     MsmPlan P = make_plan(n, c);
     size_t tot = 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * n * (c > 16 ? 4 : 2)); // digits (a batch of j jobs passes nw = j * W)
+    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * n * 2); // digits (a batch of j jobs passes nw = j * W)
+    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * ((n + 63) / 64) * 8); // their sign bits (17-bit windows)
     tot += al((size_t)nw * P.slices * 1024 * 4);             // pass-A histogram / cursors (<= 1024 bins)
     tot += al((size_t)nw * 1024 * 4 + 256);                  // bin starts
     tot += al((size_t)nw * 1024 * 4 + 256);                  // bin totals
@@ -967,7 +994,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     uint8_t* p = ws.base;
-    void* digits = (void*)p; p += al((size_t)std::max<size_t>(P.W, nw) * n * (c > 16 ? 4 : 2));
+    void* digits = (void*)p; p += al((size_t)std::max<size_t>(P.W, nw) * n * 2);
+    unsigned long long* signs = (unsigned long long*)p; p += al((size_t)std::max<size_t>(P.W, nw) * ((n + 63) / 64) * 8);
     uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * 1024 * 4);
     uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
     uint32_t* bintot = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
@@ -995,18 +1023,18 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     ScalarSets sets{};
     for (int j = 0; j < jobs; j++) sets.p[j] = (const uint32_t*)d_scalars_v[j];
     const bool wide = c > 16; // 17-bit windows: signed digits up to +-2^16
-    if (wide) msm_digits_kernel<int32_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int32_t*)digits, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
-    else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
+    if (wide) msm_digits_kernel<uint16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (uint16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
+    else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
-    if (wide) sortA_hist_kernel<int32_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int32_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
-    else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
+    if (wide) sortA_hist_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
+    else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
     sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
     sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
     sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
-    if (wide) sortA_scatter_kernel<int32_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int32_t*)digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
+    if (wide) sortA_scatter_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
                                                                    slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
-    else sortA_scatter_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
+    else sortA_scatter_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
                                                                    slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
     sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     if (tm) HIPCHK(hipEventRecord(ev[2], st));
