@@ -111,7 +111,7 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs)
     // saved is n fewer mixed additions: measured on the resident prover (tools/plonk_bench.py), 2^16 gates 3.58 ms at c = 12,
     // 3.40 / 3.54 / 3.36 / 3.40 at c = 13 / 14 / 15 / 16; 2^18 gates 7.51 ms at c = 14, 7.19 at c = 15, 7.20 at c = 16
     if (n >= ((size_t)1 << 16) && c < 15) c = 15;
-    // 17-bit windows (15 instead of 16 of them, signed digits up to +-2^16 kept as int32, 2^16 buckets): one n-th fewer mixed additions.
+    // 17-bit windows (15 instead of 16 of them, signed digits up to +-2^16 kept as uint16 magnitude + sign bit, 2^16 buckets): one n-th fewer mixed additions.
     // Measured: single 2^20 MSM 1.611 -> 1.546 ms, two in flight 1.345 -> 1.287 ms/step (-4.3 %); prover 2^19 gates 11.89 -> 11.51 ms,
     // 2^20 gates 22.1-22.8 -> 22.0 ms; 2^18 gates unchanged (6.8 ms), so smaller tables keep c = 15
     if (n >= ((size_t)1 << 19)) c = 17;
