@@ -13,6 +13,7 @@
 
 #include "bbgpu_internal.h"
 #include "host_g1.hpp"
+#include "host_small.hpp"
 #include "poly.h"
 
 namespace bbgpu {
@@ -35,7 +36,24 @@ struct SrsEntry {
     bool live;
     uint32_t* d_tab = nullptr; // pre-shifted window tables [tab_W][n], or null
     int tab_c = 0, tab_W = 0;
+    // Address-keyed lookups are only trusted after a CONTENT check: one 64-bit hash per base point (the even table entry the kernels
+    // read), taken when the table was uploaded.  A lookup re-hashes the first, the last and up to 14 evenly spaced rows of the range
+    // the caller passed (it never touches host memory outside that range: the old table may have been freed) and compares.
+    std::vector<uint64_t> row_hash;
+    bool auto_registered = false; // created by a host-pointer MSM on first sight: evictable (stale contents, overlap, LRU under the byte cap)
+    uint64_t last_use = 0;
+    size_t bytes = 0; // device bytes held (points + window tables)
 };
+
+inline uint64_t hash_row(const uint64_t* row8)
+{
+    uint64_t h = 0x9e3779b97f4a7c15ULL;
+    for (int i = 0; i < 8; i++) {
+        h = (h ^ row8[i]) * 0xbf58476d1ce4e5b9ULL;
+        h ^= h >> 29;
+    }
+    return h;
+}
 
 struct Context {
     bool ready = false;
@@ -53,6 +71,18 @@ struct Context {
     size_t scratch_cap = 0;
     bool timing = false;
     bool precompute = true; // build window tables for registered SRS (bbgpu_set_precompute)
+    uint64_t use_clock = 0;  // LRU clock of the SRS cache
+    size_t srs_cache_cap = (size_t)16 << 30; // device bytes the auto-registered tables may hold together (BBGPU_SRS_CACHE_BYTES)
+    // SURVEY 8b "small sizes": host-pointer MSMs of at most host_msm_max points against tables that are not resident, and host-buffer
+    // transforms of at most host_ntt_max elements, are answered on the host (host_small.hpp); bbgpu_set_host_thresholds / BBGPU_HOST_MSM_MAX /
+    // BBGPU_HOST_NTT_MAX.  Defaults from tools/host_path.py on MI355X + EPYC 9575F
+    int host_msm_max = 32;
+    int host_ntt_max = 16;
+    bool host_env_read = false;
+    // Workspaces shared by every caller (NTT scratch, polynomial temporaries): users on different streams are chained by this event
+    hipEvent_t shared_done = nullptr;
+    hipStream_t shared_last = nullptr;
+    bool shared_used = false;
     poly::Scratch poly_scratch; // workspace of the resident polynomial helpers
     uint64_t* d_poly_tmp = nullptr;
     size_t poly_tmp_cap = 0;
@@ -71,6 +101,14 @@ Context g_ctx;
         }                                                                                                              \
     } while (0)
 
+void read_host_env()
+{
+    if (g_ctx.host_env_read) return;
+    g_ctx.host_env_read = true;
+    if (const char* e = getenv("BBGPU_HOST_MSM_MAX")) g_ctx.host_msm_max = atoi(e);
+    if (const char* e = getenv("BBGPU_HOST_NTT_MAX")) g_ctx.host_ntt_max = std::min(64, atoi(e));
+}
+
 int ensure_init()
 {
     if (g_ctx.ready) return BBGPU_OK;
@@ -81,7 +119,26 @@ int ensure_init()
     }
     CHK(hipSetDevice(g_ctx.device));
     CHK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    CHK(hipEventCreateWithFlags(&g_ctx.shared_done, hipEventDisableTiming));
+    g_ctx.shared_used = false;
+    if (const char* e = getenv("BBGPU_SRS_CACHE_BYTES")) g_ctx.srs_cache_cap = (size_t)strtoull(e, nullptr, 0);
     g_ctx.ready = true;
+    return BBGPU_OK;
+}
+
+// The NTT scratch and the polynomial temporaries are one set of buffers for all callers.  A call on stream `st` first waits (on the
+// device) for the last user if that was another stream, and leaves its own completion event behind: two transforms issued back to
+// back on two streams then run one after the other instead of overwriting each other's intermediate data.
+int shared_begin(hipStream_t st)
+{
+    if (g_ctx.shared_used && g_ctx.shared_last != st) CHK(hipStreamWaitEvent(st, g_ctx.shared_done, 0));
+    return BBGPU_OK;
+}
+int shared_end(hipStream_t st)
+{
+    CHK(hipEventRecord(g_ctx.shared_done, st));
+    g_ctx.shared_last = st;
+    g_ctx.shared_used = true;
     return BBGPU_OK;
 }
 
@@ -98,14 +155,39 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
 
 constexpr size_t AUTO_REGISTER_MIN_POINTS = 1024; // host-pointer MSMs against unknown tables below this size do not cache the table
 
-// registers resident points; builds the pre-shifted window tables when enabled and the 24-bit row index allows it
-int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs)
+void free_entry(SrsEntry& e)
+{
+    // an asynchronous MSM may still be reading the table: drain the device first (rare path)
+    (void)hipDeviceSynchronize();
+    if (e.d_srs) (void)hipFree(e.d_srs);
+    if (e.d_tab) (void)hipFree(e.d_tab);
+    e.d_srs = e.d_tab = nullptr;
+    e.live = false;
+    e.row_hash.clear();
+    e.row_hash.shrink_to_fit();
+}
+bool ranges_overlap(const SrsEntry& e, const uint64_t* p, size_t n)
+{
+    const uint8_t *a0 = (const uint8_t*)e.host_ptr, *a1 = a0 + e.n * 128, *b0 = (const uint8_t*)p, *b1 = b0 + n * 128;
+    return a0 < b1 && b0 < a1;
+}
+
+// registers resident points; builds the pre-shifted window tables when enabled and the 24-bit row index allows it.
+// An auto-registered table first evicts the auto-registered tables it overlaps in host memory (they are what used to live there) and
+// the least recently used ones beyond the byte cap.
+int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_registered)
 {
     SrsEntry e;
     e.host_ptr = host_ptr;
     e.n = n;
     e.d_srs = d_srs;
     e.live = true;
+    e.auto_registered = auto_registered;
+    e.last_use = ++g_ctx.use_clock;
+    if (host_ptr) {
+        e.row_hash.resize(n);
+        for (size_t i = 0; i < n; i++) e.row_hash[i] = hash_row(host_ptr + i * 16);
+    }
     int c = msm_choose_c(n);
     // with tables every window feeds one shared bucket set, so wider windows only cost bucket-reduction depth while each one
     // saved is n fewer mixed additions: measured on the resident prover (tools/plonk_bench.py), 2^16 gates 3.58 ms at c = 12,
@@ -117,13 +199,33 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs)
     if (n >= ((size_t)1 << 19)) c = 17;
     if (const char* ev = getenv("BBGPU_TABLE_C")) c = std::min(17, std::max(4, atoi(ev))); // tuning knob: window size of the tables
     const int W = msm_num_windows(c);
-    if (g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24)) {
+    const bool want_tab = g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24);
+    e.bytes = n * 64 + (want_tab ? (size_t)W * n * 64 : 0);
+    if (auto_registered) {
+        for (auto& o : g_ctx.srs)
+            if (o.live && o.auto_registered && o.host_ptr && host_ptr && ranges_overlap(o, host_ptr, n)) free_entry(o);
+        for (;;) {
+            size_t held = 0;
+            SrsEntry* lru = nullptr;
+            for (auto& o : g_ctx.srs)
+                if (o.live && o.auto_registered) {
+                    held += o.bytes;
+                    if (!lru || o.last_use < lru->last_use) lru = &o;
+                }
+            if (!lru || held + e.bytes <= g_ctx.srs_cache_cap) break;
+            free_entry(*lru);
+        }
+    }
+    if (want_tab) {
         int rc = srs_build_table(d_srs, n, c, W, &e.d_tab, g_ctx.stream);
-        if (rc) return rc;
+        if (rc) {
+            (void)hipFree(d_srs);
+            return rc;
+        }
         e.tab_c = c;
         e.tab_W = W;
     }
-    g_ctx.srs.push_back(e);
+    g_ctx.srs.push_back(std::move(e));
     return (int)g_ctx.srs.size() - 1;
 }
 int entry_windows(const SrsEntry& e, size_t n)
@@ -135,11 +237,26 @@ int issue_on_entry(MsmSlot& S, const SrsEntry& e, size_t off, const uint64_t* d_
     return msm_issue(S, e.d_srs + off * 16, e.d_tab ? e.d_tab + off * 16 : nullptr, e.n, e.tab_c, d_scalars, n, wb, we, st, g_ctx.timing);
 }
 
-// table lookup by host address: returns entry index and point offset, or -1
+// does the host range [points, points + n) still hold what entry e was uploaded from (rows off .. off + n)?
+bool contents_match(const SrsEntry& e, size_t off, const uint64_t* points, size_t n)
+{
+    if (e.row_hash.size() != e.n) return false;
+    const size_t samples = n <= 16 ? n : 16;
+    for (size_t k = 0; k < samples; k++) {
+        const size_t i = samples == n ? k : (size_t)(((unsigned __int128)k * (n - 1)) / (samples - 1));
+        if (hash_row(points + i * 16) != e.row_hash[off + i]) return false;
+    }
+    return true;
+}
+
+// table lookup by host address, VALIDATED by content: returns entry index and point offset, or -1.  An auto-registered table whose
+// address range matches but whose contents do not (the caller freed the table and another landed there, or refilled the buffer) is
+// evicted; an explicitly registered one is merely not served (its handle stays valid for the device-pointer entries; in-place mutation
+// of a registered table requires bbgpu_srs_release, see bbgpu.h).  Newest entries first.
 int find_srs(const uint64_t* points, size_t n, size_t* offset)
 {
-    for (size_t i = 0; i < g_ctx.srs.size(); i++) {
-        const SrsEntry& e = g_ctx.srs[i];
+    for (size_t k = g_ctx.srs.size(); k-- > 0;) {
+        SrsEntry& e = g_ctx.srs[k];
         if (!e.live || !e.host_ptr) continue;
         const uint8_t* b = (const uint8_t*)e.host_ptr;
         const uint8_t* p = (const uint8_t*)points;
@@ -147,8 +264,13 @@ int find_srs(const uint64_t* points, size_t n, size_t* offset)
         const size_t d = (size_t)(p - b);
         if (d % 128) continue;
         if (d / 128 + n > e.n) continue;
+        if (!contents_match(e, d / 128, points, n)) {
+            if (e.auto_registered) free_entry(e);
+            continue;
+        }
+        e.last_use = ++g_ctx.use_clock;
         *offset = d / 128;
-        return (int)i;
+        return (int)k;
     }
     return -1;
 }
@@ -177,6 +299,15 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
     }
     size_t off = 0;
     int idx = find_srs(points, n, &off);
+    read_host_env();
+    if (idx < 0 && n <= (size_t)g_ctx.host_msm_max) { // the verifier's ~20 freshly built points: no allocation, no launch
+        host::g1_to_normalised(host::msm_small(scalars, points, n), out);
+        return BBGPU_OK;
+    }
+    {
+        int rc = ensure_init();
+        if (rc) return rc;
+    }
     // A table that was never registered and is too small to be an SRS (the verifier's ~20 freshly built points,
     // verifier.cpp:359-363) is used once and forgotten: caching it by address would both leak device memory per call and
     // serve stale points when the caller's vector is freed and its address reused.  Larger unknown tables are taken to be a
@@ -193,7 +324,7 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
             transient.d_srs = d;
             transient.live = true;
         } else {
-            idx = add_srs(points, n, d);
+            idx = add_srs(points, n, d, true);
             if (idx < 0) return idx;
         }
         off = 0;
@@ -302,8 +433,10 @@ int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* con
     }
     rc = grow(&g_ctx.d_scratch, &g_ctx.scratch_cap, n * 32);
     if (rc) return rc;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    hipStream_t st = (hipStream_t)hip_stream; /* NULL = the legacy default stream, as bbgpu.h says */
+    if ((rc = shared_begin(st)) != BBGPU_OK) return rc;
     rc = ntt_device(d_coeffs, g_ctx.d_scratch, lg, kind, constant, st);
+    if (rc == BBGPU_OK) rc = shared_end(st);
     if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^28)", lg);
     if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
     return rc;
@@ -325,8 +458,10 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
     }
     rc = grow(&g_ctx.d_scratch, &g_ctx.scratch_cap, (size_t)batch * n * 32);
     if (rc) return rc;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    hipStream_t st = (hipStream_t)hip_stream; /* NULL = the legacy default stream, as bbgpu.h says */
+    if ((rc = shared_begin(st)) != BBGPU_OK) return rc;
     rc = ntt_device_batch(d_coeffs, stride_elems, batch, g_ctx.d_scratch, lg, kind, constant, st);
+    if (rc == BBGPU_OK) rc = shared_end(st);
     if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^28)", lg);
     if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
     return rc;
@@ -335,9 +470,16 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
 int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!coeffs) return BBGPU_ERR_ARG;
+    read_host_env();
+    if (n <= (size_t)g_ctx.host_ntt_max && log2_exact(n) >= 1 && kind >= 0 && kind <= BBGPU_COSET_FFT_WITH_CONSTANT) {
+        const bool has_const = (kind == BBGPU_FFT_WITH_CONSTANT || kind == BBGPU_IFFT_WITH_CONSTANT || kind == BBGPU_COSET_FFT_WITH_CONSTANT);
+        if (has_const && !constant) return BBGPU_ERR_ARG;
+        host::ntt_small(coeffs, log2_exact(n), kind, constant); // SURVEY 8b small sizes: no copy, no launch
+        return BBGPU_OK;
+    }
     int rc = ensure_init();
     if (rc) return rc;
-    if (!coeffs) return BBGPU_ERR_ARG;
     rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
     if (rc) return rc;
     CHK(hipMemcpyAsync(g_ctx.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
@@ -349,6 +491,10 @@ int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
 }
 
 /* ---- resident polynomial helpers ---- */
+struct SharedGuard { // records "this stream is done with the shared workspaces" on every way out of a helper
+    hipStream_t st;
+    ~SharedGuard() { (void)shared_end(st); }
+};
 #define POLY_ENTER(ptr_ok)                                                                                              \
     std::lock_guard<std::recursive_mutex> lk(g_mu);                                                                     \
     {                                                                                                                   \
@@ -359,7 +505,9 @@ int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
             return BBGPU_ERR_ARG;                                                                                       \
         }                                                                                                               \
     }                                                                                                                   \
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream
+    hipStream_t st = (hipStream_t)hip_stream; /* NULL = the legacy default stream, as bbgpu.h says */                                               \
+    if (int rcb_ = shared_begin(st)) return rcb_;                                                                       \
+    SharedGuard shared_guard_{ st }
 
 static host::Fr load_fr(const uint64_t z[4])
 {
@@ -562,11 +710,14 @@ int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n)
     if (!points_endo_table || n == 0) return BBGPU_ERR_ARG;
     size_t off;
     int idx = find_srs(points_endo_table, n, &off);
-    if (idx >= 0 && off == 0) return idx;
+    if (idx >= 0 && off == 0) {
+        g_ctx.srs[idx].auto_registered = false; // the caller now holds the handle: never evicted behind its back
+        return idx;
+    }
     uint32_t* d = nullptr;
     rc = srs_upload(points_endo_table, n, &d, g_ctx.stream);
     if (rc) return rc;
-    return add_srs(points_endo_table, n, d);
+    return add_srs(points_endo_table, n, d, false);
 }
 
 int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out)
@@ -578,7 +729,7 @@ int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_tab
     uint32_t* d = nullptr;
     rc = srs_generate(x_mont, n, &d, host_endo_table_out, g_ctx.stream);
     if (rc) return rc;
-    return add_srs(host_endo_table_out, n, d);
+    return add_srs(host_endo_table_out, n, d, false);
 }
 
 // io.hpp:36-182 restated for the G1 part: 28-byte manifest of seven big-endian uint32 (fields 5 = num_g1_points), then points as
@@ -648,12 +799,7 @@ int bbgpu_srs_release(int handle)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (handle < 0 || handle >= (int)g_ctx.srs.size() || !g_ctx.srs[handle].live) return BBGPU_ERR_ARG;
-    (void)hipStreamSynchronize(g_ctx.stream);
-    (void)hipFree(g_ctx.srs[handle].d_srs);
-    if (g_ctx.srs[handle].d_tab) (void)hipFree(g_ctx.srs[handle].d_tab);
-    g_ctx.srs[handle].live = false;
-    g_ctx.srs[handle].d_srs = nullptr;
-    g_ctx.srs[handle].d_tab = nullptr;
+    free_entry(g_ctx.srs[handle]);
     return BBGPU_OK;
 }
 
@@ -677,16 +823,21 @@ void bbgpu_set_precompute(int enabled)
 int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12])
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    int rc = ensure_init();
-    if (rc) return rc;
-    return msm_host_ptrs(scalars, points_endo_table, n, out);
+    return msm_host_ptrs(scalars, points_endo_table, n, out); // binds the device itself unless the host answers (n = 0, tiny unknown tables)
+}
+
+void bbgpu_set_host_thresholds(int msm_max_points, int ntt_max_elements)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    g_ctx.host_env_read = true;
+    g_ctx.host_msm_max = msm_max_points < 0 ? 0 : msm_max_points;
+    g_ctx.host_ntt_max = ntt_max_elements < 0 ? 0 : std::min(64, ntt_max_elements);
 }
 
 int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    int rc = BBGPU_OK;
     if (num_jobs == 0) return BBGPU_OK;
     if (!jobs) return BBGPU_ERR_ARG;
     for (size_t i = 1; i < num_jobs; i++) {
@@ -697,13 +848,15 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
         }
     }
     const size_t n = jobs[0].num_elements;
-    if (n == 0 || g_ctx.slot[0].pending || g_ctx.slot[1].pending) {
+    read_host_env();
+    if (n == 0 || n <= (size_t)g_ctx.host_msm_max || g_ctx.slot[0].pending || g_ctx.slot[1].pending) {
         for (size_t i = 0; i < num_jobs; i++) {
             rc = msm_host_ptrs(jobs[i].scalars, jobs[i].points, jobs[i].num_elements, jobs[i].output);
             if (rc) return rc;
         }
         return BBGPU_OK;
     }
+    if ((rc = ensure_init()) != BBGPU_OK) return rc;
     // Two-slot pipeline over the jobs of a prover round (3/1/3/2 MSMs, prover.cpp:65-122,650-658): job i+1's scalars
     // cross PCIe and its kernels are enqueued while job i's bucket-reduction tail and host finish run.
     uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
@@ -721,7 +874,7 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
             uint32_t* d = nullptr;
             int r = srs_upload(jobs[i].points, n, &d, g_ctx.stream);
             if (r) return r;
-            idx = add_srs(jobs[i].points, n, d);
+            idx = add_srs(jobs[i].points, n, d, true);
             if (idx < 0) return idx;
         }
         int r = grow(stage[t], cap[t], n * 32);

@@ -1,4 +1,4 @@
-// fe.cuh -- 256-bit prime-field arithmetic for gfx950 as integer MAC chains.
+// fe.hpp -- 256-bit prime-field arithmetic for gfx950 as integer MAC chains.
 //
 // Replaces, on the device, the reference's 4x64-bit Montgomery layer
 // (src/barretenberg/fields/field_impl_int128.tcc:72-137,149-263; asm twin asm_macros.hpp:141-413).
@@ -20,6 +20,13 @@
 #include <stdint.h>
 
 #include "bn254_params.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__) && !defined(BBGPU_NO_MONT_ASM)
+#define BBGPU_MONT_ASM 1
+#include "fe_mont_gfx950.h"
+#else
+#define BBGPU_MONT_ASM 0
+#endif
 
 #if defined(__HIPCC__)
 #define BB_HD __host__ __device__ __forceinline__
@@ -156,25 +163,24 @@ template <class F, int L, int V> BB_HD Fe<F, 1, V> carry_full(const Fe<F, L, V>&
 
 // ---- Montgomery multiplication, R = 2^261 -----------------------------------------------------------------------
 // every column sum is <= 9*(L1*U)*(L2*U) + 9*2^58 + carry < 2^64 whenever L1*L2 <= 6.
-// acc = a*b + c.  LLVM sums a column's products first and adds the incoming carry with a separate v_lshl_add_u64
-// (17 per multiplication).  Forcing the carry into the first v_mad_u64_u32 with an asm statement removes them and was
-// measured at +2..5 % in the bare multiplier loop (tools/ubench/ubench_mul2.hip) but within noise (< 1 %) on the MSM and
-// NTT kernels, so the plain expression stays; define BBGPU_ASM_MAD to get the asm form.
+// On the device the three products below are the hand-scheduled gfx950 sequences of fe_mont_gfx950.h (generated by
+// tools/gen_mont_asm.py): hipcc schedules the C++ form with a separate 64-bit addition per column (v_lshl_add_u64) and
+// 277 instructions per multiplication, the asm form takes the carry as the addend of the column's first v_mad_u64_u32 (205).
+// The C++ form stays the definition: it is what the host build runs (tests/cpp/test_fe_host.cpp) and what
+// -DBBGPU_NO_MONT_ASM selects on the device (A/B, and the device self-test compares both against the reference's vectors).
 BB_HD uint64_t mad_carry_in(uint32_t a, uint32_t b, uint64_t c)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BBGPU_ASM_MAD)
-    uint64_t r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
-    return r;
-#else
     return (uint64_t)a * b + c;
-#endif
 }
 
 // Fused product scanning: one 64-bit accumulator walks the 18 columns; the carry out of column k is the addend of the
 // first multiply-add of column k+1, so there is no column array and no 64-bit carry addition.
 template <class F> BB_HD void mul_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], uint32_t (&out)[NL])
 {
+#if BBGPU_MONT_ASM
+    mul_raw_gfx950<F>(a, b, out);
+    return;
+#endif
     uint32_t m[NL];
     uint64_t acc = 0;
 #pragma unroll
@@ -203,6 +209,10 @@ template <class F> BB_HD void mul_raw(const uint32_t (&a)[NL], const uint32_t (&
 
 template <class F> BB_HD void sqr_raw(const uint32_t (&a)[NL], uint32_t (&out)[NL])
 {
+#if BBGPU_MONT_ASM
+    sqr_raw_gfx950<F>(a, out);
+    return;
+#endif
     uint32_t a2[NL], m[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a[i] << 1;
@@ -242,6 +252,10 @@ template <class F> BB_HD void sqr_raw(const uint32_t (&a)[NL], uint32_t (&out)[N
 template <class F>
 BB_HD void mul2_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&c)[NL], const uint32_t (&d)[NL], uint32_t (&out)[NL])
 {
+#if BBGPU_MONT_ASM
+    mul2_raw_gfx950<F>(a, b, c, d, out);
+    return;
+#endif
     uint32_t m[NL];
     uint64_t acc = 0;
 #pragma unroll

@@ -1,4 +1,4 @@
-// g1.cuh -- BN254 G1 (y^2 = x^3 + 3) group law for the MSM kernels, extended-Jacobian ("XYZZ") coordinates:
+// g1.hpp -- BN254 G1 (y^2 = x^3 + 3) group law for the MSM kernels, extended-Jacobian ("XYZZ") coordinates:
 //   x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2; infinity <=> ZZ == 0 (all limbs zero).
 // Replaces, on the device, g1::mixed_add / add / dbl (src/barretenberg/groups/group.hpp:153-448).  The reference
 // uses Jacobian (7M+4S mixed add, 11M+5S add); XYZZ needs 8M+2S / 12M+2S with cheaper squarings and, more
@@ -7,7 +7,7 @@
 // All exceptional cases of the group law (P+P, P+(-P), infinity operands) are handled exactly, because outputs are
 // compared bit-for-bit with the reference after normalisation.
 #pragma once
-#include "fe.cuh"
+#include "fe.hpp"
 
 namespace bbgpu {
 

@@ -9,7 +9,7 @@
 #include <string.h>
 
 #include "bn254_params.h"
-#include "fe.cuh"
+#include "fe.hpp"
 
 namespace bbgpu {
 namespace host {

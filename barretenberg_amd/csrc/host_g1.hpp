@@ -3,7 +3,7 @@
 // reference's own memory format (fields/field.hpp:19-22), so results can be handed straight back to the caller.
 // This is product code: it does NOT use oracle/.  Semantics restated from field_impl_int128.tcc:72-137,248-255
 // (Montgomery product with one final conditional subtraction); point formulas are the standard XYZZ ones used on the
-// device (g1.cuh), any representative being legal before normalisation.
+// device (g1.hpp), any representative being legal before normalisation.
 #pragma once
 #include <stdint.h>
 #include <string.h>

@@ -30,7 +30,7 @@
 #include <vector>
 
 #include "bbgpu_internal.h"
-#include "g1.cuh"
+#include "g1.hpp"
 #include "host_g1.hpp"
 
 namespace bbgpu {
@@ -858,28 +858,42 @@ static MsmPlan make_plan(size_t n, int c)
     return P;
 }
 
-// workspace sizes in bytes for a window range of `nw` windows
+// The ONE description of the workspace: byte offsets of every array for `nw` (job, window) pairs.  Both the size request
+// (MsmWorkspace::bytes_needed) and the carve in msm_issue_batch read it, and the issue path checks `end` against the
+// allocation before anything is launched.  (Round 1's only GPU memory fault -- gpurun_out/quick1.txt, first 2^20 bring-up --
+// came from exactly such a pair of hand-kept formulas: the fold arena was sized by a guess, (2 nw nb + 4096) points, while
+// the then per-level fold / slice chain bumped rows + columns + slices per window past it into the next page.)
+struct MsmCarve {
+    size_t digits, signs, histA, binstart, bintot, tmp_entries, gstart, totals, heavy, sorted, partials, buckets, arena, texp, end;
+    size_t chunks_cap;
+};
+static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
+{
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    MsmCarve L;
+    size_t p = 0;
+    const size_t wmax = std::max<size_t>(P.W, nw); // a batch of j jobs passes nw = j * W
+    L.digits = p;      p += al(wmax * n * 2);
+    L.signs = p;       p += al(wmax * ((n + 63) / 64) * 8);      // sign bits of 17-bit windows
+    L.histA = p;       p += al(nw * P.slices * 1024 * 4);        // pass-A histogram / cursors (<= 1024 bins)
+    L.binstart = p;    p += al(nw * 1024 * 4 + 256);
+    L.bintot = p;      p += al(nw * 1024 * 4 + 256);
+    L.tmp_entries = p; p += al(nw * n * 4);                      // pass-A output
+    L.gstart = p;      p += al((nw * P.nb + 1) * 4);
+    L.totals = p;      p += al(nw * 8 + 512);                    // totals, bases (nw + 1)
+    L.heavy = p;       p += al((nw * P.nb + 1) * 4);             // heavy-bucket queue
+    L.sorted = p;      p += al(nw * n * 4);
+    L.chunks_cap = (n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1;     // upper bound for any chunk length >= MIN_CHUNK
+    L.partials = p;    p += al((nw * P.nb + L.chunks_cap) * RAW_WORDS * 4);
+    L.buckets = p;     p += al(nw * P.nb * 128);
+    L.arena = p;       p += al(arena_points(P, (uint32_t)nw) * 128); // row sums + column sums
+    L.texp = p;        p += al(nw * 64 * 128);                   // exported T points
+    L.end = p;
+    return L;
+}
 size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
 {
-    MsmPlan P = make_plan(n, c);
-    size_t tot = 0;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * n * 2); // digits (a batch of j jobs passes nw = j * W)
-    tot += al((size_t)std::max<size_t>(P.W, (size_t)nw) * ((n + 63) / 64) * 8); // their sign bits (17-bit windows)
-    tot += al((size_t)nw * P.slices * 1024 * 4);             // pass-A histogram / cursors (<= 1024 bins)
-    tot += al((size_t)nw * 1024 * 4 + 256);                  // bin starts
-    tot += al((size_t)nw * 1024 * 4 + 256);                  // bin totals
-    tot += al((size_t)nw * n * 4);                           // pass-A output
-    tot += al(((size_t)nw * P.nb + 1) * 4);                  // gstart
-    tot += al((size_t)nw * 8 + 512);                         // totals, bases (nw + 1)
-    tot += al(((size_t)nw * P.nb + 1) * 4);                  // heavy-bucket queue
-    tot += al((size_t)nw * n * 4);                           // sorted
-    const size_t chunks = ((size_t)n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1; // upper bound for any chunk length >= MIN_CHUNK
-    tot += al(((size_t)nw * P.nb + chunks) * RAW_WORDS * 4); // partials
-    tot += al((size_t)nw * P.nb * 128);                      // buckets
-    tot += al(arena_points(P, (uint32_t)nw) * 128);          // fold arena
-    tot += al((size_t)nw * 64 * 128);                        // exported T points
-    return tot;
+    return carve(make_plan(n, c), n, (size_t)nw).end;
 }
 
 int MsmWorkspace::ensure(size_t bytes)
@@ -992,23 +1006,33 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, 64 * 64 * 128));
     if (!S.done) HIPCHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
 
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    uint8_t* p = ws.base;
-    void* digits = (void*)p; p += al((size_t)std::max<size_t>(P.W, nw) * n * 2);
-    unsigned long long* signs = (unsigned long long*)p; p += al((size_t)std::max<size_t>(P.W, nw) * ((n + 63) / 64) * 8);
-    uint32_t* histA = (uint32_t*)p; p += al((size_t)nw * P.slices * 1024 * 4);
-    uint32_t* binstart = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
-    uint32_t* bintot = (uint32_t*)p; p += al((size_t)nw * 1024 * 4 + 256);
-    uint32_t* tmp_entries = (uint32_t*)p; p += al((size_t)nw * n * 4);
-    uint32_t* gstart = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
-    uint32_t* totals = (uint32_t*)p; uint32_t* bases = totals + nw; p += al((size_t)nw * 8 + 512);
-    uint32_t* heavy = (uint32_t*)p; p += al(((size_t)nw * P.nb + 1) * 4);
-    uint32_t* sorted = (uint32_t*)p; p += al((size_t)nw * n * 4);
-    const size_t chunks_cap = ((size_t)n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1;
-    uint32_t* partials = (uint32_t*)p; p += al(((size_t)nw * P.nb + chunks_cap) * RAW_WORDS * 4);
-    uint32_t* buckets = (uint32_t*)p; p += al((size_t)nw * P.nb * 128);
-    uint32_t* scratch = (uint32_t*)p; p += al(arena_points(P, nw) * 128);
-    uint32_t* texp = (uint32_t*)p;
+    const MsmCarve LY = carve(P, n, nw);
+    if (LY.end > ws.cap) { // cannot happen while bytes_needed and this carve share one table; checked before anything is launched
+        set_error("internal: MSM workspace of %zu bytes, layout needs %zu (n=%zu c=%d nw=%u)", ws.cap, LY.end, n, c, nw);
+        return BBGPU_ERR_STATE;
+    }
+    uint8_t* const p = ws.base;
+    void* digits = (void*)(p + LY.digits);
+    unsigned long long* signs = (unsigned long long*)(p + LY.signs);
+    uint32_t* histA = (uint32_t*)(p + LY.histA);
+    uint32_t* binstart = (uint32_t*)(p + LY.binstart);
+    uint32_t* bintot = (uint32_t*)(p + LY.bintot);
+    uint32_t* tmp_entries = (uint32_t*)(p + LY.tmp_entries);
+    uint32_t* gstart = (uint32_t*)(p + LY.gstart);
+    uint32_t* totals = (uint32_t*)(p + LY.totals);
+    uint32_t* bases = totals + nw;
+    uint32_t* heavy = (uint32_t*)(p + LY.heavy);
+    uint32_t* sorted = (uint32_t*)(p + LY.sorted);
+    uint32_t* partials = (uint32_t*)(p + LY.partials);
+    uint32_t* buckets = (uint32_t*)(p + LY.buckets);
+    uint32_t* scratch = (uint32_t*)(p + LY.arena);
+    uint32_t* texp = (uint32_t*)(p + LY.texp);
+    // launch-shape checks against the carve (the kernels index these arrays from these quantities)
+    if ((uint64_t)G * slices * sort_bins > (uint64_t)nw * P.slices * 1024 || sort_bins > 1024 ||
+        (size_t)G * ((size_t)(1u << P.hbits) + (size_t)(1u << P.lbits)) + 64 > arena_points(P, nw)) {
+        set_error("internal: MSM launch shape exceeds the workspace layout");
+        return BBGPU_ERR_STATE;
+    }
 
     hipEvent_t* ev = S.ev;
     const bool tm = want_timing;

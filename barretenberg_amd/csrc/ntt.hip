@@ -14,7 +14,7 @@
 //   Coset / inverse / constant scalings are fused into the first load and the last store.
 //   Data stays in the reference's Montgomery(2^256) form end to end: only twiddles live in our 2^261 form, since
 //   mont261(x * 2^256, w * 2^261) = x w 2^256.
-// Field arithmetic: fe.cuh (9 x 29-bit limbs, lazy; ~163 v_mad_u64_u32 per multiply).  The kernels are bound by
+// Field arithmetic: fe.hpp (9 x 29-bit limbs, lazy; ~163 v_mad_u64_u32 per multiply).  The kernels are bound by
 // the integer VALU rate, not HBM: (n/2) log2 n + ~2n multiplies at ~1.4e11 mul/s.
 #include <hip/hip_runtime.h>
 
@@ -25,7 +25,7 @@
 #include <unordered_map>
 
 #include "bbgpu_internal.h"
-#include "fe.cuh"
+#include "fe.hpp"
 
 namespace bbgpu {
 
@@ -382,7 +382,22 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
     if ((e = pow_table(&D->scale_hi[0], 1u << (log2n - D->lo_bits), h_pow2k(g, D->lo_bits), one, st)) != hipSuccess) return e;
     if ((e = pow_table(&D->scale_lo[1], 1u << D->lo_bits, gi, one, st)) != hipSuccess) return e;
     if ((e = pow_table(&D->scale_hi[1], 1u << (log2n - D->lo_bits), h_pow2k(gi, D->lo_bits), ninv, st)) != hipSuccess) return e;
-    return hipSuccess;
+    // the tables are published to every later caller, whatever stream it runs on: they must be COMPLETE before get_domain returns
+    // (once per domain size; an event per table set would only save this one wait)
+    return hipStreamSynchronize(st);
+}
+
+void free_domain(DomainTables* D)
+{
+    for (int i = 0; i < 2; i++) {
+        for (int p = 0; p < 2; p++) if (D->tw_sub[i][p]) (void)hipFree(D->tw_sub[i][p]);
+        if (D->tw_sub3[i]) (void)hipFree(D->tw_sub3[i]);
+        if (D->twist_lo[i]) (void)hipFree(D->twist_lo[i]);
+        if (D->twist_hi[i]) (void)hipFree(D->twist_hi[i]);
+        if (D->scale_lo[i]) (void)hipFree(D->scale_lo[i]);
+        if (D->scale_hi[i]) (void)hipFree(D->scale_hi[i]);
+    }
+    delete D;
 }
 
 hipError_t get_domain(int log2n, hipStream_t st, DomainTables** out)
@@ -398,7 +413,8 @@ hipError_t get_domain(int log2n, hipStream_t st, DomainTables** out)
     DomainTables* D = new DomainTables();
     hipError_t e = build_domain(D, log2n, st);
     if (e != hipSuccess) {
-        delete D;
+        (void)hipStreamSynchronize(st); // kernels of the tables built so far
+        free_domain(D);                 // including the partially built set
         return e;
     }
     g_domains[dev * 64 + log2n] = D;
@@ -610,18 +626,7 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
 void ntt_release_tables()
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_domains) {
-        DomainTables* D = kv.second;
-        for (int i = 0; i < 2; i++) {
-            for (int p = 0; p < 2; p++) if (D->tw_sub[i][p]) (void)hipFree(D->tw_sub[i][p]);
-            if (D->tw_sub3[i]) (void)hipFree(D->tw_sub3[i]);
-            if (D->twist_lo[i]) (void)hipFree(D->twist_lo[i]);
-            if (D->twist_hi[i]) (void)hipFree(D->twist_hi[i]);
-            if (D->scale_lo[i]) (void)hipFree(D->scale_lo[i]);
-            if (D->scale_hi[i]) (void)hipFree(D->scale_hi[i]);
-        }
-        delete D;
-    }
+    for (auto& kv : g_domains) free_domain(kv.second);
     g_domains.clear();
 }
 

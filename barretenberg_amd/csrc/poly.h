@@ -4,7 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "fe.cuh"
+#include "fe.hpp"
 #include "host_fr.hpp"
 
 namespace bbgpu {

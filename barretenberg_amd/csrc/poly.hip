@@ -32,7 +32,7 @@
 #include <vector>
 
 #include "bbgpu_internal.h"
-#include "fe.cuh"
+#include "fe.hpp"
 #include "host_fr.hpp"
 #include "poly.h"
 

@@ -53,8 +53,14 @@ const char* bbgpu_version(void);
  * Drop-in for polynomial_arithmetic::{fft,ifft,coset_fft,coset_ifft,fft_with_constant,ifft_with_constant,
  * coset_fft_with_constant}(fr::field_t* coeffs, const evaluation_domain& domain[, const fr::field_t& constant]):
  * transforms coeffs[0..n) in place.  `constant` (4 limbs, Montgomery) is read for the *_with_constant kinds only.
- * bbgpu_ntt: host buffer (copied to the device and back).  bbgpu_ntt_device: device-resident buffer, asynchronous on
- * `hip_stream` (a hipStream_t, may be NULL for the default stream). */
+ * bbgpu_ntt: host buffer (copied to the device and back; n <= 16 is answered on the host, see bbgpu_set_host_thresholds).
+ * bbgpu_ntt_device: device-resident buffer, asynchronous on `hip_stream` (a hipStream_t; NULL = the legacy default stream, so a
+ * caller working on the null stream is ordered with the transform as with its own kernels).  The same holds
+ * for the polynomial helpers below.  The MSM device entries differ: there NULL selects the ticket's own internal NON-BLOCKING stream
+ * (that is what lets consecutive MSMs overlap), which has no implicit ordering with the caller's null stream -- d_scalars must be
+ * complete before the call (synchronise, or pass the producing stream).
+ * Calls on different streams may be in flight together: the library's shared scratch is handed from one stream to the next by an
+ * event (they serialise on the device, results are independent of the interleaving). */
 int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant);
 int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* constant, void* hip_stream);
 /* `batch` (<= 64) transforms of the same size and kind in one set of launches; transform j occupies
@@ -68,6 +74,12 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
  * kernels' working form; it returns a handle >= 0.  Host-pointer MSM calls look the table up by address (and register
  * it on first sight), so sub-slices `points + 2*off` of a registered table are served from the resident copy
  * (batched_scalar_multiplications slices exactly like that, scalar_multiplication.cpp:720-726). */
+/* The address is only a hint: every address hit is re-validated against a per-point content fingerprint taken at upload (first, last
+ * and 14 evenly spaced rows of the range the caller passes; only memory inside that range is read).  A table that was registered on
+ * first sight and whose memory now holds other points (freed and reused, or refilled in place) is evicted and uploaded again;
+ * tables registered on first sight are also evicted least-recently-used beyond BBGPU_SRS_CACHE_BYTES (default 16 GiB of device
+ * memory).  A table registered EXPLICITLY keeps its handle until bbgpu_srs_release: mutate it in place only after releasing it
+ * (host-pointer calls stop being served from a handle whose contents changed, device-pointer calls by handle cannot notice). */
 int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
 /* Registration also builds, on the device, the pre-shifted window tables 2^(c w) * P_i (the reference's
  * generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129): W x n x 64 bytes (1 GiB at n = 2^20), so that
@@ -90,6 +102,12 @@ int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_tab
 /* drop-in for scalar_multiplication::pippenger(scalars, points, n, bucket_width) (:457-476); scalars not modified.
  * out = {x, y, z} normalised, or infinity flag set (n == 0, all-zero scalars). */
 int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12]);
+/* SURVEY 8b "small sizes": the reference's callers include the Verifier's per-proof MSM over ~20 freshly built points
+ * (verifier.cpp:359-363) and proofs of n = 4 circuits (test_verifier.cpp:105-122).  Host-pointer MSMs of at most `msm_max_points`
+ * points against a table that is not resident, and host-buffer transforms (bbgpu_ntt) of at most `ntt_max_elements` (<= 64)
+ * elements, are answered on the host by csrc/host_small.hpp -- no device allocation, copy or launch; results identical.  Defaults
+ * 32 / 16 (env BBGPU_HOST_MSM_MAX / BBGPU_HOST_NTT_MAX); 0 / 0 sends every size to the GPU.  Nothing larger ever runs on the host. */
+void bbgpu_set_host_thresholds(int msm_max_points, int ntt_max_elements);
 
 /* drop-in for scalar_multiplication::batched_scalar_multiplications(mul_state, num) (:650-772); layout-identical to
  * multiplication_state (scalar_multiplication.hpp:88-94: points@0, scalars@8, num_elements@16, output@32, size 128) */
@@ -138,7 +156,7 @@ int bbgpu_g1_sum(const uint64_t* points12, size_t count, uint64_t out[12]);
 /* ---- resident polynomial helpers -------------------------------------------------------------------
  * The O(n) loops of the prover that sit between the transforms and the commitments, on device-resident vectors in the
  * reference's memory format (n x 4 limbs, Montgomery; any representative below 2^256 in, canonical out).  All are
- * asynchronous on `hip_stream` (NULL = the library's stream) except where a host value is returned. */
+ * asynchronous on `hip_stream` (NULL = the legacy default stream) except where a host value is returned. */
 /* polynomial_arithmetic::evaluate(coeffs, z, n) (polynomial_arithmetic.cpp:337-373): sum_i coeffs[i] z^i, canonical */
 int bbgpu_fr_evaluate_device(const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4], void* hip_stream);
 /* fr::batch_invert(coeffs, n) (fields/field.hpp:503-522), in place; every element must be non-zero */

@@ -1,11 +1,11 @@
-// Host-side unit test of barretenberg_amd/csrc/fe.cuh + g1.cuh (the exact code the HIP kernels run) against the
+// Host-side unit test of barretenberg_amd/csrc/fe.hpp + g1.hpp (the exact code the HIP kernels run) against the
 // oracle (oracle/bn254_oracle.c).  Test infrastructure: links liboracle.so.  Built and run by tests/test_host_field.py.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
-#include "../../barretenberg_amd/csrc/g1.cuh"
+#include "../../barretenberg_amd/csrc/g1.hpp"
 #include "../../oracle/bn254_oracle.h"
 
 using namespace bbgpu;

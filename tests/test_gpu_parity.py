@@ -14,6 +14,7 @@ def gpu(request):
     """every test runs twice: with the pre-shifted SRS window tables (default) and without (bbgpu_set_precompute(0))"""
     from barretenberg_amd import BbGpu
     g = BbGpu(device=0)
+    g.set_host_thresholds(0, 0)  # every size on the GPU kernels (the host answers to tiny sizes are tested in tests/test_host_small.py)
     g.set_precompute(request.param == "window-tables")
     yield g
     g.shutdown()

@@ -39,9 +39,9 @@ def test_fails_loudly_without_gpu(lib):
         pytest.skip("GPU present")
     from barretenberg_amd import BbGpuError
     with pytest.raises(BbGpuError, match="no HIP device"):
-        lib.fft(np.zeros((4, 4), dtype=np.uint64))
-    with pytest.raises(BbGpuError):
-        lib.pippenger(np.zeros((4, 4), dtype=np.uint64), np.zeros((8, 8), dtype=np.uint64), 4)
+        lib.fft(np.zeros((64, 4), dtype=np.uint64))
+    with pytest.raises(BbGpuError, match="no HIP device"):
+        lib.pippenger(np.zeros((64, 4), dtype=np.uint64), np.zeros((128, 8), dtype=np.uint64), 64)
 
 
 def test_product_does_not_import_oracle():
@@ -86,7 +86,7 @@ def _neg(oracle, p):
 
 
 def test_host_field_code_matches_oracle():
-    """fe.cuh / g1.cuh (the code the kernels run) compiled for the host and checked against the oracle"""
+    """fe.hpp / g1.hpp (the code the kernels run) compiled for the host and checked against the oracle"""
     exe = "/tmp/bbgpu_test_fe_host"
     src = os.path.join(ROOT, "tests", "cpp", "test_fe_host.cpp")
     ob = os.path.join(ROOT, "oracle", "_build")

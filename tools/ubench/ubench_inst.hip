@@ -50,6 +50,10 @@ __global__ void __launch_bounds__(256) NAME(uint64_t* out, uint32_t sa, uint32_t
 #define OP_LSHR64(i) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(a[i]));
 #define OP_LSHR32(i) asm volatile("v_lshrrev_b32 %0, 29, %0" : "+v"(a[i]));
 #define OP_MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(x));
+#define OP_MAD64S(i) asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(a[i]) : "v"(x), "s"(sb) : "s10", "s11");
+#define OP_ANDLIT(i) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(a[i]));
+#define OP_MULLOS(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "s"(sb));
+#define OP_LSHL64(i) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(a[i]));
 #define OP_DOT4(i) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
 
 KERNEL(k_mad64, DECL64, OP_MAD64, FOLD64)
@@ -72,6 +76,10 @@ KERNEL(k_dot4, DECL32, OP_DOT4, FOLD32)
 KERNEL(k_lshr64, DECL64, OP_LSHR64, FOLD64)
 KERNEL(k_lshr32, DECL32, OP_LSHR32, FOLD32)
 KERNEL(k_mov, DECL32, OP_MOV, FOLD32)
+KERNEL(k_mad64s, DECL64, OP_MAD64S, FOLD64)
+KERNEL(k_andlit, DECL32, OP_ANDLIT, FOLD32)
+KERNEL(k_mullos, DECL32, OP_MULLOS, FOLD32)
+KERNEL(k_lshl64, DECL64, OP_LSHL64, FOLD64)
 
 typedef void (*kern_t)(uint64_t*, uint32_t, uint32_t);
 struct Entry { const char* name; kern_t k; };
@@ -81,16 +89,16 @@ int main() {
                 {"v_add_co_u32", k_addco}, {"v_addc_co_u32", k_addc}, {"v_add3_u32", k_add3}, {"v_mad_u32_u24", k_mad24},
                 {"v_mul_hi_u32_u24", k_mulhi24}, {"v_lshl_add_u64", k_lshladd64}, {"v_fma_f64", k_fma64},
                 {"v_alignbit_b32", k_alignbit}, {"v_cndmask_b32", k_cndmask}, {"v_and_b32", k_and}, {"v_mad_u32_u16", k_madu16},
-                {"v_pk_fma_f32", k_pkfma32}, {"v_dot4_u32_u8", k_dot4}, {"v_lshrrev_b64", k_lshr64}, {"v_lshrrev_b32", k_lshr32}, {"v_mov_b32", k_mov}};
+                {"v_pk_fma_f32", k_pkfma32}, {"v_dot4_u32_u8", k_dot4}, {"v_lshrrev_b64", k_lshr64}, {"v_lshrrev_b32", k_lshr32}, {"v_mov_b32", k_mov}, {"v_mad_u64_u32(sgpr)", k_mad64s}, {"v_and_b32(literal)", k_andlit}, {"v_mul_lo_u32(sgpr)", k_mullos}, {"v_lshlrev_b64", k_lshl64}};
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   int cus = prop.multiProcessorCount;
   printf("device %s CUs %d clock %d kHz\n", prop.name, cus, prop.clockRate);
   uint64_t* d; size_t maxthreads = (size_t)cus * 8 * 256; CHECK(hipMalloc(&d, (maxthreads + maxthreads / 64) * 8));
   std::vector<uint64_t> h(maxthreads + maxthreads / 64);
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  printf("%-18s %6s %12s %14s %16s\n", "instr", "w/SIMD", "ms", "cyc/wave-inst", "Gwaveinst/s/chip");
+  printf("%-22s %6s %12s %14s %16s\n", "instr", "w/SIMD", "ms", "cyc/wave-inst", "Gwaveinst/s/chip");
   for (auto& e : es) {
-    for (int wps : {1, 2, 4, 8}) {
+    for (int wps : {1, 2, 3, 4, 8}) {
       int blocks = cus * wps;  // 256 threads = 4 waves = 1 wave per SIMD per block
       hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d, 3u, 5u);
       CHECK(hipDeviceSynchronize());
@@ -103,7 +111,7 @@ int main() {
       double cyc = 0; for (size_t w = 0; w < nt / 64; ++w) cyc += (double)h[nt + w]; cyc /= (nt / 64);
       double ninst = (double)ITERS * 16;
       // per-SIMD issue cost: cycles elapsed per wave / instr per wave / waves sharing the SIMD
-      printf("%-18s %6d %12.4f %14.3f %16.2f\n", e.name, wps, ms, cyc / ninst / wps, (double)(nt / 64) * ninst / (ms * 1e-3) / 1e9);
+      printf("%-22s %6d %12.4f %14.3f %16.2f\n", e.name, wps, ms, cyc / ninst / wps, (double)(nt / 64) * ninst / (ms * 1e-3) / 1e9);
     }
   }
   return 0;

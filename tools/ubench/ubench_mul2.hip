@@ -1,8 +1,8 @@
-// multiplier codegen experiments on the product header (fe.cuh): throughput of mul / sqr chains, bit-checked on host
+// multiplier codegen experiments on the product header (fe.hpp): throughput of mul / sqr chains, bit-checked on host
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
-#include "../../barretenberg_amd/csrc/fe.cuh"
+#include "../../barretenberg_amd/csrc/fe.hpp"
 using namespace bbgpu;
 #define CHECK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1;}}while(0)
 #define NCHAIN 512
@@ -20,7 +20,7 @@ template <int MODE> __global__ void __launch_bounds__(256) k(uint32_t* io)
 int main()
 {
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0)); int cus = prop.multiProcessorCount;
-    for (int wps : {2, 4}) {
+    for (int wps : {1, 2, 3, 4}) {
         size_t nt = (size_t)cus * wps * 256;
         std::vector<uint32_t> h(nt * 18);
         uint64_t st = 12345; for (auto& v : h) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; v = (uint32_t)(st >> 35) & 0x1fffffff; }
