@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_msm_g1",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
-    "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds",
+    "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_selftest_field", "bbgpu_selftest_g1",
     "bbgpu_set_timing",
     "bbgpu_fr_evaluate_device", "bbgpu_fr_batch_invert_device", "bbgpu_fr_product_scan_device", "bbgpu_fr_mul_device",
     "bbgpu_kate_opening_device", "bbgpu_lagrange_l1_fft_device", "bbgpu_divide_by_pseudo_vanishing_device",
@@ -212,6 +212,12 @@ class BbGpu:
         self._chk(self.lib.bbgpu_transcript_read_g1(path.encode(), degree, _ptr(table)))
         return table
 
+    def srs_cache_stats(self):
+        """(live tables, of which registered on first sight, device bytes those hold)"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_uint64(0)
+        self._chk(self.lib.bbgpu_srs_cache_stats(C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def srs_release(self, handle):
         self._chk(self.lib.bbgpu_srs_release(handle))
 
@@ -288,6 +294,29 @@ class BbGpu:
         points12 = np.ascontiguousarray(points12, dtype=np.uint64).reshape(-1, 12)
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.lib.bbgpu_g1_sum(_ptr(points12), points12.shape[0], _ptr(out)))
+        return out
+
+    # ---- device self-test (known-answer entry points of the field / group layer) ---------------------------------------
+    SELFTEST_FIELD_OPS = {"mul": 0, "sqr": 1, "add": 2, "sub": 3, "neg": 4, "mul_add": 5, "mul_sub": 6, "lazy_limbs": 7, "lazy_weak": 8,
+                          "lazy_value": 9, "reduce": 10, "sqr_lazy": 11, "zero_tests": 12}
+    SELFTEST_G1_OPS = {"madd": 0, "add": 1, "dbl": 2, "dbl_affine": 3}
+
+    def selftest_field(self, field, op, a, b):
+        """field: 'fq' | 'fr'; a, b: (n, 4) uint64 Montgomery operands -> (n, 4) canonical results of the DEVICE arithmetic"""
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros_like(a)
+        self.lib.bbgpu_selftest_field.argtypes = [C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]
+        self._chk(self.lib.bbgpu_selftest_field({"fq": 0, "fr": 1}[field], self.SELFTEST_FIELD_OPS[op], _ptr(a), _ptr(b), a.shape[0], _ptr(out)))
+        return out
+
+    def selftest_g1(self, op, p, q):
+        """p, q: (n, 12) uint64 Jacobian -> (n, 16): X, Y, ZZ, ZZZ of the device result"""
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 12)
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, 12)
+        out = np.zeros((p.shape[0], 16), dtype=np.uint64)
+        self.lib.bbgpu_selftest_g1.argtypes = [C.c_int, u64p, u64p, C.c_size_t, u64p]
+        self._chk(self.lib.bbgpu_selftest_g1(self.SELFTEST_G1_OPS[op], _ptr(p), _ptr(q), p.shape[0], _ptr(out)))
         return out
 
     # ---- instrumentation ---------------------------------------------------------------------------------------------

@@ -803,6 +803,26 @@ int bbgpu_srs_release(int handle)
     return BBGPU_OK;
 }
 
+// resident tables right now: how many, how many of them registered on first sight (evictable), device bytes held by those
+int bbgpu_srs_cache_stats(int* live_entries, int* auto_entries, uint64_t* auto_bytes)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int live = 0, au = 0;
+    uint64_t bytes = 0;
+    for (const auto& e : g_ctx.srs)
+        if (e.live) {
+            live++;
+            if (e.auto_registered) {
+                au++;
+                bytes += e.bytes;
+            }
+        }
+    if (live_entries) *live_entries = live;
+    if (auto_entries) *auto_entries = au;
+    if (auto_bytes) *auto_bytes = bytes;
+    return BBGPU_OK;
+}
+
 /* ---- MSM ---- */
 int bbgpu_msm_num_windows(size_t n)
 {

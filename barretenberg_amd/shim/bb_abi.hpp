@@ -68,6 +68,9 @@ struct multiplication_state {
 g1::element pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width);
 void batched_scalar_multiplications(multiplication_state* mul_state, size_t num_batches);
 void generate_pippenger_point_table(g1::affine_element* points, g1::affine_element* table, size_t num_points);
+size_t get_optimal_bucket_width(const size_t num_points);
+g1::element pippenger_low_memory(fr::field_t* scalars, g1::affine_element* points, size_t num_points);
+g1::element alt_pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width);
 } // namespace scalar_multiplication
 
 namespace polynomial_arithmetic {
@@ -91,6 +94,14 @@ void divide_by_pseudo_vanishing_polynomial(fr::field_t* coeffs, const evaluation
 fr::field_t compute_kate_opening_coefficients(const fr::field_t* src, fr::field_t* dest, const fr::field_t& z, const size_t n);
 lagrange_evaluations get_lagrange_evaluations(const fr::field_t& z, const evaluation_domain& domain);
 void compress_fft(const fr::field_t* src, fr::field_t* dest, const size_t current_size, const size_t compress_factor);
+// the remaining externs of the translation unit (polynomial_arithmetic.cpp:37-127,129-264,317-335): no caller in the PLONK stack,
+// but the reference's own benchmarks and tests link against them, and a replacement of the WHOLE translation unit defines them
+void fft_inner_serial(fr::field_t* coeffs, const size_t domain_size, const std::vector<fr::field_t*>& root_table);
+void fft_inner_parallel(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& root, const std::vector<fr::field_t*>& root_table);
+void scale_by_generator(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& generator_start, const fr::field_t& generator_shift);
+void compute_multiplicative_subgroup(const size_t log2_subgroup_size, const evaluation_domain& src_domain, fr::field_t* subgroup_roots);
+void add(const fr::field_t* a_coeffs, const fr::field_t* b_coeffs, fr::field_t* r_coeffs, const evaluation_domain& domain);
+void mul(const fr::field_t* a_coeffs, const fr::field_t* b_coeffs, fr::field_t* r_coeffs, const evaluation_domain& domain);
 } // namespace polynomial_arithmetic
 
 // layout probes (measured against the reference headers with sizeof/offsetof)

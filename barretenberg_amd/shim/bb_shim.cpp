@@ -14,8 +14,14 @@
 //   polynomial_arithmetic::evaluate :337-373, copy_polynomial :23-35, compute_lagrange_polynomial_fft :381-476,
 //   divide_by_pseudo_vanishing_polynomial :478-560, compute_kate_opening_coefficients :562-591,
 //   get_lagrange_evaluations :594-626, compress_fft :629-639
-// Not defined: the CPU algorithm's internals (get_optimal_bucket_width, compute_wnaf_state, pippenger_internal, fft_inner_*,
-// scale_by_generator, the experimental alt_pippenger family): nothing outside their own translation unit, tests and benches calls them.
+// and the translation units' remaining externs, which only the reference's own tests and benchmarks call
+// (bench_barretenberg.cpp:613-624 fft_inner_serial): get_optimal_bucket_width :21-81; fft_inner_serial :37-79, fft_inner_parallel
+// :129-264 (forwarded to the GPU transform), scale_by_generator :81-102, compute_multiplicative_subgroup :104-127, add / mul :317-335
+// -- O(n) host loops on csrc/host_fr.hpp, canonical outputs.
+// plus pippenger_low_memory / alt_pippenger (same sum, same arguments).
+// Not defined: the CPU Pippenger's private machinery (compute_wnaf_state, compute_next_bucket_index, pippenger_internal,
+// alt_pippenger_internal) whose argument types are the CPU algorithm's own state structs, and the pippenger_precomputed family
+// (generate_pippenger_precompute_table hands back the CPU layout of per-round tables; the GPU keeps its own window tables resident).
 //
 // Error behaviour: the reference API has no error channel.  A failing GPU call prints the library's error
 // and aborts: silently returning a wrong proof element is worse than stopping, and there is deliberately no CPU
@@ -27,6 +33,7 @@
 #include <cstring>
 
 #include "../../include/bbgpu.h"
+#include "../csrc/host_fr.hpp"
 
 namespace {
 [[noreturn]] void die(const char* what, int rc)
@@ -67,6 +74,27 @@ void generate_pippenger_point_table(g1::affine_element* points, g1::affine_eleme
 {
     int rc = bbgpu_generate_point_table(reinterpret_cast<const uint64_t*>(points), reinterpret_cast<uint64_t*>(table), num_points);
     if (rc != BBGPU_OK) die("generate_pippenger_point_table", rc);
+}
+
+// the same sum through the reference's other two (points, scalars, n) entries: pippenger_low_memory (:478-574, which is allowed to
+// clobber `scalars`; this one does not) and alt_pippenger (bench_barretenberg.cpp:487-498)
+g1::element pippenger_low_memory(fr::field_t* scalars, g1::affine_element* points, size_t num_points) { return pippenger(scalars, points, num_points, 0); }
+g1::element alt_pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width)
+{
+    return pippenger(scalars, points, num_initial_points, forced_bucket_width);
+}
+
+// scalar_multiplication.cpp:21-81: the CPU algorithm's bucket width for n points (a cost-model table; the GPU path picks its own
+// window size, callers outside the translation unit only read this for bookkeeping).  SURVEY a8: 2^20 -> 15, 2^16 -> 12, 8192 -> 10, 1 -> 1
+size_t get_optimal_bucket_width(const size_t num_points)
+{
+    static const struct { size_t at_least, width; } table[] = {
+        { 14617149, 21 }, { 2139094, 18 }, { 100000, 15 }, { 144834, 14 }, { 25067, 12 }, { 13926, 11 }, { 7659, 10 },
+        { 2436, 9 },      { 376, 7 },      { 231, 6 },     { 97, 5 },      { 35, 4 },     { 10, 3 },     { 2, 2 },
+    };
+    for (const auto& row : table)
+        if (num_points >= row.at_least) return row.width;
+    return 1;
 }
 
 } // namespace scalar_multiplication
@@ -132,6 +160,95 @@ void compress_fft(const fr::field_t* src, fr::field_t* dest, const size_t curren
     while (((size_t)1 << log2_factor) < compress_factor) ++log2_factor;
     const size_t new_size = current_size >> log2_factor;
     for (size_t i = 0; i < new_size; ++i) dest[i] = src[i << log2_factor]; // ascending: dest may overlap the front of src (:629-639)
+}
+
+// ---- the translation unit's remaining externs: host restatements (no caller on the prover path) ------------------------------------
+namespace {
+using bbgpu::host::Fr;
+inline Fr ld(const fr::field_t& a)
+{
+    Fr r;
+    std::memcpy(r.d, a.data, 32);
+    return r;
+}
+inline void st(fr::field_t& a, const Fr& v) { std::memcpy(a.data, v.d, 32); }
+inline Fr canon(const fr::field_t& a) { return bbgpu::host::fr_mul(ld(a), bbgpu::host::fr_one()); } // any 256-bit representative -> [0, r)
+} // namespace
+
+// :81-102  coeffs[i] *= generator_start * generator_shift^i
+void scale_by_generator(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& generator_start, const fr::field_t& generator_shift)
+{
+    using namespace bbgpu::host;
+    const Fr shift = canon(generator_shift);
+    Fr work = canon(generator_start);
+    for (size_t i = 0; i < domain.size; ++i) {
+        st(coeffs[i], fr_mul(ld(coeffs[i]), work));
+        work = fr_mul(work, shift);
+    }
+}
+// :104-127  subgroup_roots[i] = g^n * w_k^i, k = 2^log2_subgroup_size, n = src_domain.size, g = the coset generator 5
+void compute_multiplicative_subgroup(const size_t log2_subgroup_size, const evaluation_domain& src_domain, fr::field_t* subgroup_roots)
+{
+    using namespace bbgpu::host;
+    const Fr root = fr_root_of_unity((int)log2_subgroup_size);
+    Fr acc = fr_from_limbs(bbgpu::FrHostP::GEN5);
+    for (size_t i = 0; i < src_domain.log2_size; ++i) acc = fr_sqr(acc);
+    for (size_t i = 0; i < ((size_t)1 << log2_subgroup_size); ++i) {
+        st(subgroup_roots[i], acc);
+        acc = fr_mul(acc, root);
+    }
+}
+// :317-335  pointwise over the domain
+void add(const fr::field_t* a_coeffs, const fr::field_t* b_coeffs, fr::field_t* r_coeffs, const evaluation_domain& domain)
+{
+    for (size_t i = 0; i < domain.size; ++i) st(r_coeffs[i], bbgpu::host::fr_add(canon(a_coeffs[i]), canon(b_coeffs[i])));
+}
+void mul(const fr::field_t* a_coeffs, const fr::field_t* b_coeffs, fr::field_t* r_coeffs, const evaluation_domain& domain)
+{
+    for (size_t i = 0; i < domain.size; ++i) st(r_coeffs[i], bbgpu::host::fr_mul(ld(a_coeffs[i]), canon(b_coeffs[i])));
+}
+// :37-79  the single-threaded in-place transform over the caller's round-root table (bench-only in the reference, and kept a CPU
+// symbol: SURVEY a20): bit-reversal, then log2 n rounds; root_table[s - 1][j] = w_{2m}^j for round m = 2^s.  Outputs canonical.
+void fft_inner_serial(fr::field_t* coeffs, const size_t domain_size, const std::vector<fr::field_t*>& root_table)
+{
+    using namespace bbgpu::host;
+    size_t log2_size = 0;
+    while (((size_t)1 << log2_size) < domain_size) ++log2_size;
+    for (size_t i = 0; i < domain_size; ++i) {
+        size_t j = 0;
+        for (size_t b = 0; b < log2_size; ++b) j |= ((i >> b) & 1) << (log2_size - 1 - b);
+        if (i < j) {
+            const fr::field_t t = coeffs[i];
+            coeffs[i] = coeffs[j];
+            coeffs[j] = t;
+        }
+    }
+    for (size_t i = 0; i < domain_size; ++i) st(coeffs[i], canon(coeffs[i]));
+    for (size_t m = 1, s = 0; m < domain_size; m *= 2, ++s) {
+        for (size_t k = 0; k < domain_size; k += 2 * m) {
+            for (size_t j = 0; j < m; ++j) {
+                const Fr x = ld(coeffs[k + j]);
+                const Fr t = m == 1 ? ld(coeffs[k + j + m]) : fr_mul(ld(root_table[s - 1][j]), ld(coeffs[k + j + m]));
+                st(coeffs[k + j + m], fr_sub(x, t));
+                st(coeffs[k + j], fr_add(x, t));
+            }
+        }
+    }
+}
+// :129-264  the multi-threaded transform fft() and ifft() are built on: `root` says which of the two (the domain's root or its
+// inverse; no scaling by 1/n in either case).  Forwarded to the GPU transform: ifft_with_constant(n) = the unscaled inverse transform.
+void fft_inner_parallel(fr::field_t* coeffs, const evaluation_domain& domain, const fr::field_t& root, const std::vector<fr::field_t*>&)
+{
+    if (!std::memcmp(root.data, domain.root.data, 32)) {
+        run(coeffs, domain, BBGPU_FFT, nullptr);
+    } else if (!std::memcmp(root.data, domain.root_inverse.data, 32)) {
+        fr::field_t n;
+        st(n, bbgpu::host::fr_from_u64((uint64_t)domain.size));
+        run(coeffs, domain, BBGPU_IFFT_WITH_CONSTANT, &n);
+    } else {
+        std::fprintf(stderr, "bbgpu shim: fft_inner_parallel with a root that is neither the domain's root nor its inverse\n");
+        std::abort();
+    }
 }
 } // namespace polynomial_arithmetic
 } // namespace barretenberg

@@ -90,6 +90,8 @@ void bbgpu_set_precompute(int enabled);
  * shard windows over ranks: a table carries the window size it was built for) */
 int bbgpu_srs_num_windows(int srs_handle, size_t n);
 int bbgpu_srs_release(int handle);
+/* resident tables right now: all, those registered on first sight (evictable), and the device bytes the latter hold (any may be NULL) */
+int bbgpu_srs_cache_stats(int* live_entries, int* auto_entries, uint64_t* auto_bytes);
 /* io::read_transcript, G1 part (io/io.hpp:36-182): reads `degree - 1` points of an ignition-format transcript file
  * (srs_db/transcript.dat) behind the generator and writes the 2 * degree entry endomorphism table of
  * generate_pippenger_point_table -- the `monomials` array of ReferenceString (reference_string.cpp:16-35) -- ready for
@@ -231,6 +233,37 @@ int bbgpu_plonk_last_timing(int prover, double ms_out[4]);     /* construct_proo
 int bbgpu_plonk_prover_destroy(int prover);
 /* challenge.hpp:64-112 recomputed from a finished proof: gamma, beta, alpha, z (4 limbs each).  Host only, no GPU needed. */
 int bbgpu_plonk_challenges_from_proof(const uint64_t proof[BBGPU_PLONK_PROOF_WORDS], uint64_t out[16]);
+
+/* ---- device self-test: known-answer entry points for the field and group layer ------------------------------------
+ * One GPU lane per case runs the device arithmetic every kernel is built from (csrc/fe.hpp incl. the gfx950 asm products, csrc/g1.hpp);
+ * operands and results in the reference's memory format, canonical.  What each op returns (a, b = the operands' residues):
+ * field_impl_int128.tcc:72-137,149-263 / group.hpp:153-448 semantics. */
+enum {
+    BBGPU_SELFTEST_MUL = 0,        /* a b                         field::__mul          */
+    BBGPU_SELFTEST_SQR = 1,        /* a^2                         field::__sqr          */
+    BBGPU_SELFTEST_ADD = 2,        /* a + b                       field::__add          */
+    BBGPU_SELFTEST_SUB = 3,        /* a - b                       field::__sub          */
+    BBGPU_SELFTEST_NEG = 4,        /* -a                          field::__neg          */
+    BBGPU_SELFTEST_MUL_ADD = 5,    /* a b + (a + b)(a - b)        two products, one Montgomery reduction */
+    BBGPU_SELFTEST_MUL_SUB = 6,    /* a b - 2 a b                 the same with a negated operand */
+    BBGPU_SELFTEST_LAZY_LIMBS = 7, /* 2a 3b                       unnormalised limbs at the multiplier's limit */
+    BBGPU_SELFTEST_LAZY_WEAK = 8,  /* 4a (b - a)                  limbs beyond it: renormalised inside mul() */
+    BBGPU_SELFTEST_LAZY_VALUE = 9, /* 28 a                        value bound at its maximum, 168 p < 2^261, through the multiplier */
+    BBGPU_SELFTEST_REDUCE = 10,    /* 28 a                        the same through reduce_value() */
+    BBGPU_SELFTEST_SQR_LAZY = 11,  /* (2a - b)^2 */
+    BBGPU_SELFTEST_ZERO_TESTS = 12 /* limb 0: bit 0 = (a - b == 0), bit 1 = ((a - b) a == 0) */
+};
+enum {
+    BBGPU_SELFTEST_G1_MADD = 0,      /* p + q_affine (negated when bit 0 of q's z limb 0 is set)  g1::mixed_add, group.hpp:219-322 */
+    BBGPU_SELFTEST_G1_ADD = 1,       /* p + q                                                      g1::add, :324-448 */
+    BBGPU_SELFTEST_G1_DBL = 2,       /* 2 p                                                        g1::dbl, :153-217 */
+    BBGPU_SELFTEST_G1_DBL_AFFINE = 3 /* 2 p for an affine p (the P + P branch of the mixed addition) */
+};
+/* field: 0 = fq, 1 = fr; a, b, out: n x 4 limbs */
+int bbgpu_selftest_field(int field, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* p, q: n x 12 limbs (Jacobian {x, y, z}, infinity flag honoured); out: n x 16 limbs {X, Y, ZZ, ZZZ} with x = X / ZZ, y = Y / ZZZ,
+ * ZZ = 0 for infinity (the kernels' extended-Jacobian form; the caller normalises) */
+int bbgpu_selftest_g1(int op, const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out);
 
 /* ---- instrumentation (bench.py) ---------------------------------------------------------------------------------
  * Device time in milliseconds of the kernels launched by the most recent bbgpu_*_device call on this thread, measured

@@ -1,0 +1,155 @@
+"""Drop-in boundary behaviour on the GPU (-m gpu): the address-keyed SRS cache follows the CONTENTS of the caller's memory,
+asynchronous entries on different streams do not share intermediate data, NULL means the default stream for the transforms,
+and the one exchange step of the multi-GPU MSM runs over RCCL (backend nccl) even on one GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FR_MODULUS, aligned_copy, aligned_empty
+from tests.util import NTT_SEED, SCALAR_SEED, SRS_SEED, limbs, noncanonical
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from barretenberg_amd import BbGpu
+    os.environ["BBGPU_SRS_CACHE_BYTES"] = str(12 << 20)  # room for two 2048-point tables with their window tables (4.9 MiB each)
+    g = BbGpu(device=0)
+    g.set_host_thresholds(0, 0)
+    yield g
+    g.shutdown()
+    del os.environ["BBGPU_SRS_CACHE_BYTES"]
+
+
+@pytest.fixture(scope="module")
+def tables(oracle):
+    """three different 2048-point SRS (different secrets) as endo tables, a 24-point one, and scalars"""
+    out = []
+    for k in range(3):
+        x = oracle.random_scalars(SRS_SEED + 17 * k, 1)[0]
+        out.append(oracle.point_table(oracle.make_srs(x, 2048)))
+    small = oracle.point_table(oracle.make_srs(oracle.random_scalars(SRS_SEED + 99, 1)[0], 24))
+    return out, small, oracle.random_scalars(SCALAR_SEED, 2048)
+
+
+def test_srs_cache_follows_buffer_contents(gpu, oracle, tables):
+    """a table registered on first sight must not be served after its memory holds other points --
+    refilled in place (n >= 1024), replaced by a different-size table at the same address, or a small table at an interior address"""
+    (A, B, C), small, sc = tables
+    n = 2048
+    buf = aligned_empty((2 * n, 8))
+    buf[:] = A
+    assert np.array_equal(gpu.pippenger(sc, buf, n)[:8], oracle.msm_affine(sc, A, n)[:8])
+    live0, auto0, _ = gpu.srs_cache_stats()
+    assert auto0 >= 1
+    buf[:] = B                                     # same address, same size, other points
+    assert np.array_equal(gpu.pippenger(sc, buf, n)[:8], oracle.msm_affine(sc, B, n)[:8])
+    assert gpu.srs_cache_stats()[1] == auto0       # the stale entry was evicted, not leaked
+    buf[:2 * 1500] = C[:2 * 1500]                  # a different-size table at the same address (1500 points)
+    assert np.array_equal(gpu.pippenger(sc, buf, 1500)[:8], oracle.msm_affine(sc, aligned_copy(C[:3000]), 1500)[:8])
+    assert np.array_equal(gpu.pippenger(sc, buf, 1500)[:8], oracle.msm_affine(sc, aligned_copy(C[:3000]), 1500)[:8])  # now served from the cache
+    buf[400:448] = small                           # the verifier's freshly built 24 points at an interior address of a cached range
+    got = gpu.pippenger(aligned_copy(sc[:24]), buf[400:], 24)
+    assert np.array_equal(got[:8], oracle.msm_affine(aligned_copy(sc[:24]), small, 24)[:8])
+    # sub-slices of an unchanged cached table are still served (scalar_multiplication.cpp:720-726)
+    buf[:] = A
+    gpu.pippenger(sc, buf, n)
+    want = oracle.msm_affine(aligned_copy(sc[:300]), aligned_copy(A[200:800]), 300)
+    assert np.array_equal(gpu.pippenger(aligned_copy(sc[:300]), buf[200:], 300)[:8], want[:8])
+    # batched entry: same rule
+    buf[:] = B
+    outs = gpu.batched_scalar_multiplications([(buf, aligned_copy(sc[o:o + 1024]), 1024) for o in (0, 1024)])
+    for o, out in zip((0, 1024), outs):
+        assert np.array_equal(out[:8], oracle.msm_affine(aligned_copy(sc[o:o + 1024]), aligned_copy(B[:2048]), 1024)[:8])
+
+
+def test_explicit_registration_is_not_served_stale(gpu, oracle, tables):
+    (A, B, C), small, sc = tables
+    import torch
+    n = 2048
+    buf = aligned_empty((2 * n, 8))
+    buf[:] = C
+    h = gpu.srs_register(buf)
+    want_c = oracle.msm_affine(sc, C, n)
+    assert np.array_equal(gpu.pippenger(sc, buf, n)[:8], want_c[:8])
+    buf[:] = A                                     # mutated in place without bbgpu_srs_release (documented misuse)
+    assert np.array_equal(gpu.pippenger(sc, buf, n)[:8], oracle.msm_affine(sc, A, n)[:8])  # host-pointer calls follow the memory
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    assert np.array_equal(gpu.msm_device(h, d.data_ptr(), n)[:8], want_c[:8])              # the handle still names what was registered
+    gpu.srs_release(h)
+
+
+def test_srs_cache_lru_under_byte_cap(gpu, oracle, tables):
+    (A, B, C), small, sc = tables
+    n = 2048
+    bufs = [aligned_copy(t) for t in (A, B, C)]
+    for b, t in zip(bufs, (A, B, C)):
+        assert np.array_equal(gpu.pippenger(sc, b, n)[:8], oracle.msm_affine(sc, t, n)[:8])
+        live, auto, held = gpu.srs_cache_stats()
+        assert held <= (12 << 20), held
+    assert gpu.srs_cache_stats()[1] <= 2           # three tables seen, at most two fit the cap
+    for b, t in zip(bufs, (A, B, C)):              # evicted tables come back on demand
+        assert np.array_equal(gpu.pippenger(sc, b, n)[:8], oracle.msm_affine(sc, t, n)[:8])
+
+
+def test_two_transforms_in_flight_on_two_streams(gpu, oracle):
+    """back-to-back transforms on different streams used to share one pass-1 scratch buffer"""
+    import torch
+    n = 1 << 16
+    xs = [noncanonical(oracle.random_scalars(NTT_SEED + 31 * k, n), FR_MODULUS) for k in range(4)]
+    want = [oracle.ntt(x, "fft") for x in xs]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    ds = [torch.from_numpy(x.view(np.int64)).cuda() for x in xs]
+    torch.cuda.synchronize()
+    for _ in range(3):  # several rounds, no synchronisation in between
+        for d, s in zip(ds, streams):
+            gpu.ntt_device(d.data_ptr(), n, "fft", stream=s.cuda_stream)
+        for d, s in zip(ds, streams):
+            gpu.ntt_device(d.data_ptr(), n, "ifft", stream=s.cuda_stream)
+    for d, s in zip(ds, streams):
+        gpu.ntt_device(d.data_ptr(), n, "fft", stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for d, w in zip(ds, want):
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), w)
+
+
+def test_null_stream_is_the_default_stream(gpu, oracle):
+    """NULL = the legacy default stream: work the caller queued there is ordered with the transform"""
+    import torch
+    n = 1 << 18
+    x = oracle.random_scalars(NTT_SEED + 5, n)
+    want = oracle.ntt(x, "coset_fft")
+    d = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    h = torch.from_numpy(x.view(np.int64)).pin_memory()
+    for _ in range(3):
+        d.zero_()
+        d.copy_(h, non_blocking=True)               # producer on the default stream, not waited for
+        gpu.ntt_device(d.data_ptr(), n, "coset_fft")  # stream=None
+        out = d.clone()                              # consumer on the default stream
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+def test_partial_sum_exchange_over_rccl_world_size_1(gpu, oracle, tables):
+    """the multi-GPU MSM's one exchange step over backend nccl (= RCCL) with the ranks this box has: init, all_gather of the
+    96-byte partial sums on the GPU, identical fold -- the same objects bench.py uses for N > 1 (barretenberg_amd/sharding.py)"""
+    import torch
+    import torch.distributed as dist
+    from barretenberg_amd.sharding import PartialSumExchange, pipelined_steps
+    (A, B, C), small, sc = tables
+    n = 2048
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        h = gpu.srs_register(aligned_copy(A))
+        d = torch.from_numpy(sc.view(np.int64)).cuda()
+        ex = PartialSumExchange(gpu, 1, torch.device("cuda:0"))
+        res = pipelined_steps(3, lambda: gpu.msm_device_async(h, d.data_ptr(), n), gpu.msm_wait, ex)
+        want = oracle.msm_affine(sc, A, n)
+        assert len(res) == 3 and all(np.array_equal(r[:8], want[:8]) for r in res)
+        gpu.srs_release(h)
+    finally:
+        dist.destroy_process_group()

@@ -430,6 +430,19 @@ def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
     # host-pointer path resolves to the same resident table
     out2 = gpu.pippenger(scalars, table, n)
     assert np.array_equal(out, out2)
+    # BASELINE config 4 at full size on one GPU: the 8-way split the driver runs across 8 ranks -- eight shares of whole digit
+    # windows and (against window tables) eight row-range shares [W n r / 8, W n (r + 1) / 8) -- folded with bbgpu_g1_sum
+    W = gpu.srs_num_windows(h, n)
+    bounds = [W * r // 8 for r in range(9)]
+    parts = [gpu.msm_device(h, d_sc.data_ptr(), n, 0, a, b) for a, b in zip(bounds[:-1], bounds[1:]) if a < b]
+    _check(gpu.g1_sum(np.stack(parts)), case)
+    if gpu.srs_has_window_tables(h):
+        R = W * n
+        cuts = [R * r // 8 for r in range(9)]
+        parts = []
+        for a, b in zip(cuts[:-1], cuts[1:]):  # two in flight, like the ranks' pipelines
+            parts.append(gpu.msm_wait(gpu.msm_device_rows_async(h, d_sc.data_ptr(), n, a, b)))
+        _check(gpu.g1_sum(np.stack(parts)), case)
 
 
 def test_msm_row_range_shares_add_up(gpu, oracle, msm_small):

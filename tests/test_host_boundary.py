@@ -153,3 +153,65 @@ def test_transcript_reader_matches_reference_format(tmp_path):
         assert np.array_equal(G.read_transcript(ref_path, n), want)
     with pytest.raises(Exception):
         G.read_transcript(path, n + 5)  # more points than the file holds
+
+
+def test_shim_host_members_match_oracle(oracle):
+    """the shim's host-only TU-mates (no caller on the prover path; the reference's benches and tests link them) on seeded inputs"""
+    from oracle.pyoracle import FR
+    subprocess.run(["make", "-C", os.path.join(ROOT, "barretenberg_amd", "shim")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    exe = "/tmp/bbgpu_test_shim_host"
+    pkg = os.path.join(ROOT, "barretenberg_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shim_host.cpp"), "-L" + pkg, "-lbbshim", "-lbbgpu",
+                    "-Wl,-rpath," + pkg], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    vec, width = {}, {}
+    for line in out.splitlines():
+        t = line.split()
+        if t[0] == "width":
+            width[int(t[1])] = int(t[2])
+        else:
+            vec.setdefault(t[0], []).append(np.array([int(x, 16) for x in t[2:6]], dtype=np.uint64))
+    for n, w in width.items():
+        assert w == oracle.optimal_bucket_width(n), n  # scalar_multiplication.cpp:21-81 via the oracle (SURVEY a8: 2^20 -> 15, 2^16 -> 12, 1 -> 1)
+    assert width[1 << 20] == 15 and width[1 << 16] == 12 and width[131072] == 15 and width[8192] == 10 and width[10000] == 10 and width[1] == 1
+    a, b, g = np.stack(vec["a"]), np.stack(vec["b"]), vec["g"]
+    n = a.shape[0]
+    canon = lambda x: oracle.reduce_once(FR, oracle.reduce_once(FR, oracle.reduce_once(FR, x)))  # inputs < 2^254 < 4r
+    for i in range(n):
+        assert np.array_equal(vec["add"][i], oracle.add(FR, canon(a[i]), canon(b[i])))
+        assert np.array_equal(vec["mul"][i], canon(oracle.mul(FR, a[i], b[i])))
+    work = canon(g[0])
+    for i in range(n):  # polynomial_arithmetic.cpp:81-102
+        assert np.array_equal(vec["scale"][i], canon(oracle.mul(FR, a[i], work))), i
+        work = canon(oracle.mul(FR, work, g[1]))
+    acc = oracle.const(FR, "generator")
+    for _ in range(6):
+        acc = oracle.sqr(FR, acc)
+    root = oracle.root_of_unity(3)
+    for i in range(8):  # :104-127
+        assert np.array_equal(vec["subgroup"][i], canon(acc)), i
+        acc = oracle.mul(FR, acc, root)
+    assert np.array_equal(np.stack(vec["fft_serial"]), oracle.ntt(a, "fft"))  # :37-79 computes the same transform as fft()
+
+
+def test_shim_covers_the_replaced_translation_units():
+    """INTEGRATION recipe A replaces two whole translation units: every extern of polynomial_arithmetic.o is defined by the shim, and
+    of scalar_multiplication.o everything except the CPU algorithm's private machinery (state structs of its own) and the
+    pippenger_precomputed family.  Compared against the reference objects compiled in place (oracle/_ref/obj; skipped where absent)."""
+    obj = os.path.join(ROOT, "oracle", "_ref", "obj")
+    pa, sm = os.path.join(obj, "polynomials", "polynomial_arithmetic.o"), os.path.join(obj, "curves", "bn254", "scalar_multiplication.o")
+    if not (os.path.exists(pa) and os.path.exists(sm)):
+        pytest.skip("reference objects not built here")
+
+    def externs(path, dynamic=False):
+        out = subprocess.run(["nm"] + (["-D"] if dynamic else []) + ["--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and "barretenberg" in l.split()[2]}
+
+    shim = externs(os.path.join(ROOT, "barretenberg_amd", "libbbshim.so"), dynamic=True)
+    assert externs(pa) <= shim, sorted(externs(pa) - shim)
+    missing = externs(sm) - shim
+    allowed = ("compute_wnaf_state", "compute_next_bucket_index", "pippenger_internal", "alt_pippenger_internal", "pippenger_precomputed",
+               "pippenger_internal_precomputed", "generate_pippenger_precompute_table")
+    for m in missing:
+        assert any(a in m for a in allowed), m
+    assert len(externs(sm) & shim) >= 6
