@@ -34,7 +34,7 @@ NTT_KINDS = {
 C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
     "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
-    "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_msm_g1",
+    "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_transcript_write", "bbgpu_msm_g1",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_selftest_field", "bbgpu_selftest_g1",
@@ -212,6 +212,11 @@ class BbGpu:
         self._chk(self.lib.bbgpu_transcript_read_g1(path.encode(), degree, _ptr(table)))
         return table
 
+    def write_transcript(self, path, points_endo_table, degree, x_mont):
+        """the file io::read_transcript accepts for this SRS: degree - 1 G1 points + {G2, x G2} (io.hpp:36-182)"""
+        self.lib.bbgpu_transcript_write.argtypes = [C.c_char_p, u64p, C.c_size_t, u64p]
+        self._chk(self.lib.bbgpu_transcript_write(path.encode(), _ptr(points_endo_table), degree, _ptr(np.ascontiguousarray(x_mont, dtype=np.uint64))))
+
     def srs_cache_stats(self):
         """(live tables, of which registered on first sight, device bytes those hold)"""
         a, b, c = C.c_int(0), C.c_int(0), C.c_uint64(0)
@@ -321,7 +326,8 @@ class BbGpu:
 
     # ---- instrumentation ---------------------------------------------------------------------------------------------
     def set_timing(self, on=True):
-        self.lib.bbgpu_set_timing(1 if on else 0)
+        """False / 0: off; True / 1: an event after every stage; 2: only the accumulation kernel (light: for timed regions)"""
+        self.lib.bbgpu_set_timing(int(on))
 
     def last_timing(self):
         buf = (C.c_float * 8)()

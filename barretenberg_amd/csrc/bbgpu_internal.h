@@ -36,7 +36,7 @@ struct MsmSlot {
     hipStream_t stream = nullptr; // the slot's own stream (used when the caller passes none)
     hipEvent_t done = nullptr;
     hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    bool pending = false, trivial = false, timed = false;
+    bool pending = false, trivial = false, timed = false, timed_light = false;
     size_t n = 0;
     uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0, jobs = 1;
     uint64_t acc_seq = 0; // position of this MSM's accumulation in the process-wide sequence of timed accumulations (0 = none)
@@ -45,11 +45,11 @@ struct MsmSlot {
 int msm_choose_c(size_t n);
 int msm_num_windows(int c);
 int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
-              int we, hipStream_t st, bool want_timing);
+              int we, hipStream_t st, int want_timing);
 int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
-                    size_t n, int wb, int we, hipStream_t st, bool want_timing, uint32_t row_i0 = 0, uint32_t row_i1 = 0xffffffffu);
+                    size_t n, int wb, int we, hipStream_t st, int want_timing, uint32_t row_i0 = 0, uint32_t row_i1 = 0xffffffffu);
 int msm_issue_rows(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n,
-                   uint64_t row_begin, uint64_t row_end, hipStream_t st, bool want_timing);
+                   uint64_t row_begin, uint64_t row_end, hipStream_t st, int want_timing);
 int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing);
 int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uint32_t** d_tab_out, hipStream_t st);
 int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);

@@ -13,6 +13,7 @@
 
 #include "bbgpu_internal.h"
 #include "host_g1.hpp"
+#include "host_g2.hpp"
 #include "host_small.hpp"
 #include "poly.h"
 
@@ -69,14 +70,15 @@ struct Context {
     size_t stage2_cap = 0;
     uint64_t* d_scratch = nullptr; // NTT scratch
     size_t scratch_cap = 0;
-    bool timing = false;
+    int timing = 0; // 0 off, 1 every stage, 2 the accumulation only (bbgpu_set_timing)
     bool precompute = true; // build window tables for registered SRS (bbgpu_set_precompute)
     uint64_t use_clock = 0;  // LRU clock of the SRS cache
     size_t srs_cache_cap = (size_t)16 << 30; // device bytes the auto-registered tables may hold together (BBGPU_SRS_CACHE_BYTES)
     // SURVEY 8b "small sizes": host-pointer MSMs of at most host_msm_max points against tables that are not resident, and host-buffer
     // transforms of at most host_ntt_max elements, are answered on the host (host_small.hpp); bbgpu_set_host_thresholds / BBGPU_HOST_MSM_MAX /
-    // BBGPU_HOST_NTT_MAX.  Defaults from tools/host_path.py on MI355X + EPYC 9575F
-    int host_msm_max = 32;
+    // BBGPU_HOST_NTT_MAX.  Defaults from tools/small_sizes.py on MI355X + EPYC 9575F: MSM n = 4 / 20 / 32 / 64 host 0.16 / 0.31 / 0.41 /
+    // 0.73 ms against 0.35-0.37 ms through the kernels (crossover near 24 points); transforms n = 4 / 16 / 64 host 9 / 13 / 68 us against 37-43 us
+    int host_msm_max = 24;
     int host_ntt_max = 16;
     bool host_env_read = false;
     // Workspaces shared by every caller (NTT scratch, polynomial temporaries): users on different streams are chained by this event
@@ -406,7 +408,7 @@ void bbgpu_shutdown(void)
 void bbgpu_set_timing(int enabled)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    g_ctx.timing = enabled != 0;
+    g_ctx.timing = enabled < 0 || enabled > 2 ? 1 : enabled;
 }
 int bbgpu_last_timing(float* ms_out, int max_entries)
 {
@@ -792,6 +794,66 @@ int bbgpu_transcript_read_g1(const char* path, size_t degree, uint64_t* points_e
         done += chunk;
     }
     fclose(f);
+    return BBGPU_OK;
+}
+
+// io.hpp:36-135,159-181 restated for WRITING: the file read_transcript(monomials, g2_x, degree, path) accepts for this SRS.
+// 28-byte manifest (seven big-endian uint32: transcript_number 0, total_transcripts 1, total_g1_points, total_g2_points 2, num_g1_points,
+// num_g2_points 2, start_from 0), the degree - 1 points x G .. x^(degree-1) G (entries 2 .. 2 (degree - 1) of the endo table; entry 0, the
+// generator, is implicit in the format), then G2 and x G2, then the 64-byte checksum slot the reference never verifies (zeros).
+// Coordinates leave Montgomery form; four 64-bit limbs least-significant first, each limb big-endian.  Host only.
+int bbgpu_transcript_write(const char* path, const uint64_t* points_endo_table, size_t degree, const uint64_t x_mont[4])
+{
+    if (!path || !points_endo_table || degree < 2 || !x_mont || degree - 1 > 0xffffffffu) return BBGPU_ERR_ARG;
+    host::G2Affine xg2;
+    if (!host::g2_scalar_mul_affine(host::G2_ONE, load_fr(x_mont), &xg2)) {
+        set_error("transcript secret is zero");
+        return BBGPU_ERR_ARG;
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) {
+        set_error("cannot create transcript %s", path);
+        return BBGPU_ERR_ARG;
+    }
+    const host::Fq one_raw = { { 1, 0, 0, 0 } };
+    auto put_fq = [&](unsigned char* dst, const uint64_t* mont) {
+        host::Fq v;
+        memcpy(v.d, mont, 32);
+        v = host::fq_mul(v, one_raw); // out of Montgomery form
+        for (int l = 0; l < 4; l++)
+            for (int b = 0; b < 8; b++) dst[l * 8 + b] = (unsigned char)(v.d[l] >> (8 * (7 - b)));
+    };
+    const uint32_t man[7] = { 0, 1, (uint32_t)(degree - 1), 2, (uint32_t)(degree - 1), 2, 0 };
+    unsigned char mb[28];
+    for (int i = 0; i < 7; i++)
+        for (int b = 0; b < 4; b++) mb[4 * i + b] = (unsigned char)(man[i] >> (8 * (3 - b)));
+    bool ok = fwrite(mb, 1, 28, f) == 28;
+    std::vector<unsigned char> buf(64 * 4096);
+    for (size_t done = 1; ok && done < degree;) {
+        const size_t chunk = std::min<size_t>(4096, degree - done);
+        for (size_t k = 0; k < chunk; k++) {
+            const uint64_t* e = points_endo_table + (done + k) * 16;
+            put_fq(&buf[k * 64], e);
+            put_fq(&buf[k * 64 + 32], e + 4);
+        }
+        ok = fwrite(buf.data(), 64, chunk, f) == chunk;
+        done += chunk;
+    }
+    unsigned char g2b[2 * 128 + 64];
+    memset(g2b, 0, sizeof(g2b));
+    const host::G2Affine pts[2] = { host::G2_ONE, xg2 };
+    for (int i = 0; i < 2; i++) { // g2::affine_element = {x.c0, x.c1, y.c0, y.c1} (io.hpp:100-135)
+        put_fq(g2b + 128 * i, pts[i].x.c0.d);
+        put_fq(g2b + 128 * i + 32, pts[i].x.c1.d);
+        put_fq(g2b + 128 * i + 64, pts[i].y.c0.d);
+        put_fq(g2b + 128 * i + 96, pts[i].y.c1.d);
+    }
+    ok = ok && fwrite(g2b, 1, sizeof(g2b), f) == sizeof(g2b);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        set_error("short write to transcript %s", path);
+        return BBGPU_ERR_ARG;
+    }
     return BBGPU_OK;
 }
 

@@ -59,12 +59,19 @@ __device__ __forceinline__ void store8(uint32_t* p, const uint32_t (&w)[8])
     q[0] = make_uint4(w[0], w[1], w[2], w[3]);
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-// table entries are canonical Montgomery-261 values packed as 8 words
+// table entries are canonical Montgomery-261 values stored PRE-UNPACKED: the nine 29-bit limbs the multiplier takes, padded to
+// 12 words (three 16-byte loads, no shift/mask work per use: the packed 8-word form cost ~20 VALU instructions per twiddle, three
+// twiddles per radix-2^2 group).  The tables are tiny (n1/2 + n2/2 + 4 sqrt(n) entries), so 48 instead of 32 bytes per entry is free.
+constexpr int TW_WORDS = 12;
 __device__ __forceinline__ FeT<Fr> load_tw(const uint32_t* table, uint32_t idx)
 {
-    uint32_t w[8];
-    load8(table + 8 * (size_t)idx, w);
-    return assume_bound<1, 1>(unpack<Fr>(w));
+    const uint4* q = reinterpret_cast<const uint4*>(table + TW_WORDS * (size_t)idx);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    FeT<Fr> r;
+    r.d[0] = a.x; r.d[1] = a.y; r.d[2] = a.z; r.d[3] = a.w;
+    r.d[4] = b.x; r.d[5] = b.y; r.d[6] = b.z; r.d[7] = b.w;
+    r.d[8] = c.x;
+    return r;
 }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits)
@@ -270,7 +277,7 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
     }
 }
 
-// table[k] = base^(k * stride_exp) * factor   (all Montgomery-261), k < count; canonical packed output
+// table[k] = base^k * factor   (all Montgomery-261), k < count; canonical, as nine exact 29-bit limbs in a 12-word entry
 __global__ void ntt_pow_table_kernel(uint32_t* table, uint32_t count, Limbs9 base, Limbs9 factor)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,7 +290,11 @@ __global__ void ntt_pow_table_kernel(uint32_t* table, uint32_t count, Limbs9 bas
     }
     uint32_t w[8];
     to_canonical(acc, w);
-    store8(table + 8 * (size_t)k, w);
+    const Fe<Fr, 1, 6> u = unpack<Fr>(w); // exact limbs of the canonical value
+    uint4* q = reinterpret_cast<uint4*>(table + TW_WORDS * (size_t)k);
+    q[0] = make_uint4(u.d[0], u.d[1], u.d[2], u.d[3]);
+    q[1] = make_uint4(u.d[4], u.d[5], u.d[6], u.d[7]);
+    q[2] = make_uint4(u.d[8], 0u, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -328,7 +339,7 @@ std::unordered_map<int, DomainTables*> g_domains; // keyed by device * 64 + log2
 
 hipError_t pow_table(uint32_t** out, uint32_t count, const H& base, const H& factor, hipStream_t st)
 {
-    hipError_t e = hipMalloc((void**)out, (size_t)count * 32);
+    hipError_t e = hipMalloc((void**)out, (size_t)count * TW_WORDS * 4);
     if (e != hipSuccess) return e;
     ntt_pow_table_kernel<<<(count + 127) / 128, 128, 0, st>>>(*out, count, to_limbs(base), to_limbs(factor));
     return hipGetLastError();

@@ -29,19 +29,58 @@ from barretenberg_amd.sharding import PartialSumExchange, pipelined_steps  # noq
 
 LOG2N = 20
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-FR_TOP_MASK = 0x1FFFFFFFFFFFFFFF  # 253-bit values < r: uniformly random field elements read as Montgomery residues
+FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+SPLITMIX_GAMMA = 0x9E3779B97F4A7C15
 
 
-def random_field_elements(n, seed):
-    rng = np.random.Generator(np.random.PCG64(seed))
-    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    a[:, 3] &= np.uint64(FR_TOP_MASK)
+def splitmix64(state0, count):
+    """`count` outputs of splitmix64 started at `state0` (the synthetic-input generator), vectorised"""
+    with np.errstate(over="ignore"):
+        z = np.uint64(state0) + np.uint64(SPLITMIX_GAMMA) * np.arange(1, count + 1, dtype=np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def raw_scalars(n, state0):
+    """a scalar = 4 consecutive outputs as limbs 0..3 with limb 3 & 0x0fff...f (value < 2^252 < r), NOT yet in Montgomery form"""
+    a = splitmix64(state0, 4 * n).reshape(n, 4).copy()
+    a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
     return a
 
 
-def cpu_baseline(table, scalars, expect_xy, ntt_in, ntt_expect):
-    """Reference CPU path (oracle/_ref = the reference's own sources, x86-64 asm) timed on this box's host cores on
-    the same inputs.  Falls back to our C port when the reference build / BMI2+ADX are unavailable."""
+def limbs_of(v):
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def to_montgomery_on_device(G, raw, dev):
+    """x -> x * 2^256 mod r for a whole vector, on the GPU (one pointwise Montgomery product with 2^512 mod r); returns the device tensor"""
+    n = raw.shape[0]
+    d_raw = torch.from_numpy(raw.view(np.int64)).to(dev)
+    rsq = torch.from_numpy(limbs_of(pow(2, 512, FR_MODULUS)).view(np.int64)).to(dev)
+    d_rsq = rsq.repeat(n, 1).contiguous()
+    d_out = torch.empty_like(d_raw)
+    G.mul_device(d_out.data_ptr(), d_raw.data_ptr(), d_rsq.data_ptr(), n)
+    torch.cuda.synchronize()
+    return d_out
+
+
+def median_ms(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts)), float(min(ts))
+
+
+def cpu_baseline(table, scalars, expect_xy, ntt_in, ntt_expect, table16, expect16_xy, ntt22_in, ntt22_expect):
+    """Reference CPU path (oracle/_ref = the reference's own sources, x86-64 asm) timed on this box's host cores on the same inputs:
+    SURVEY 8d's list -- 1-thread pippenger and all-cores batched_scalar_multiplications at 2^20, config 1 (2^16, bucket widths 12 and 15,
+    bench_barretenberg.cpp:308-332), fft and coset_fft at 2^20 and 2^22 (:603-611).  Medians.  Falls back to our C port when the
+    reference build / BMI2+ADX are unavailable.  The GPU results are compared with the reference's on the way."""
     from oracle.pyoracle import Oracle, Ref, aligned_copy
     n = scalars.shape[0]
     out = {}
@@ -51,29 +90,48 @@ def cpu_baseline(table, scalars, expect_xy, ntt_in, ntt_expect):
         R = Ref(True)
         R.set_threads(threads)
         sc, tb = aligned_copy(scalars), aligned_copy(table)
-        t0 = time.perf_counter()
-        r1 = R.pippenger(sc, tb, n)  # the reference's serial pippenger(), 1 thread
-        t1 = time.perf_counter() - t0
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            rb = R.batched_msm([sc], [tb])[0]  # the entry the prover uses, all granted cores
-        tb_s = (time.perf_counter() - t0) / reps
+
+        def timed(fn, reps):
+            ts, r = [], None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                r = fn()
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)), r
+
+        t1, _ = timed(lambda: R.pippenger(sc, tb, n), 1)  # the reference's serial pippenger(), 1 thread: ~2.4 s, once
+        tb_s, rb = timed(lambda: R.batched_msm([sc], [tb])[0], 3)  # the entry the prover uses, all granted cores
         match = bool(np.array_equal(rb[:8], expect_xy))
-        co = aligned_copy(ntt_in)
-        R.prepare_domain(n)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            co[...] = ntt_in
-            R.ntt_inplace(co, "fft")
-        tn = (time.perf_counter() - t0) / reps
-        ntt_match = bool(np.array_equal(co, ntt_expect))
+        # config 1: 2^16 points, forced bucket widths 12 and 15
+        m = 1 << 16
+        sc16, tb16 = aligned_copy(scalars[:m]), aligned_copy(table16)
+        c1 = {}
+        for width in (12, 15):
+            tw, r16 = timed(lambda: R.pippenger(sc16, tb16, m, width), 3)
+            c1["width_%d_ms" % width] = tw * 1e3
+            match = match and bool(np.array_equal(R_norm(R, r16)[:8], expect16_xy))
+        # transforms
+        ntt = {}
+        ntt_match = True
+        for lg, src, expect in ((20, ntt_in, ntt_expect), (22, ntt22_in, ntt22_expect)):
+            co = aligned_copy(src)
+            R.prepare_domain(1 << lg)
+            for kind in ("fft", "coset_fft"):
+                def run():
+                    co[...] = src
+                    R.ntt_inplace(co, kind)
+                tn, _ = timed(run, 3)
+                ntt["2^%d %s" % (lg, kind)] = {"ms": tn * 1e3, "elements_per_s": (1 << lg) / tn}
+                if expect is not None and kind in expect:
+                    ntt_match = ntt_match and bool(np.array_equal(co, expect[kind]))
         out = {"value": n / tb_s, "unit": "points/s", "cores": threads, "kind": "reference",
-               "sample": "2^20-point MSM: 1x pippenger() on 1 thread (%.0f ms, %.3e points/s) + %dx batched_scalar_multiplications() on %d threads (%.0f ms each); "
-                         "2^20 fft() on %d threads %.1f ms = %.3e elements/s (includes a 32 MiB memcpy)" % (
-                             t1 * 1e3, n / t1, reps, threads, tb_s * 1e3, threads, tn * 1e3, n / tn),
-               "single_thread_value": n / t1, "ntt_value": n / tn, "gpu_result_bit_exact": match and ntt_match}
-        del r1
+               "sample": "medians: 2^20-point MSM 1x pippenger() on 1 thread (%.0f ms, %.3e points/s), 3x batched_scalar_multiplications() on %d threads (%.0f ms); "
+                         "config 1 pippenger(2^16) width 12 / 15 on 1 thread %.0f / %.0f ms; fft / coset_fft on %d threads 2^20 %.1f / %.1f ms, 2^22 %.1f / %.1f ms "
+                         "(each includes the memcpy that restores the input)" % (
+                             t1 * 1e3, n / t1, threads, tb_s * 1e3, c1["width_12_ms"], c1["width_15_ms"], threads, ntt["2^20 fft"]["ms"],
+                             ntt["2^20 coset_fft"]["ms"], ntt["2^22 fft"]["ms"], ntt["2^22 coset_fft"]["ms"]),
+               "single_thread_value": n / t1, "single_thread_ms": t1 * 1e3, "all_cores_ms": tb_s * 1e3, "config1_2e16": c1, "ntt": ntt,
+               "ntt_value": ntt["2^20 fft"]["elements_per_s"], "gpu_result_bit_exact": match and ntt_match}
     else:
         O = Oracle()
         m = 1 << 14
@@ -85,6 +143,11 @@ def cpu_baseline(table, scalars, expect_xy, ntt_in, ntt_expect):
                "gpu_result_bit_exact": None}
         del r
     return out
+
+
+def R_norm(R, p):
+    """normalised affine coordinates of a reference Jacobian result (checker only)"""
+    return R.g1_op("normalize", p)
 
 
 def plonk_leg(G, args, gates=65536, reps=10):
@@ -125,6 +188,34 @@ def plonk_leg(G, args, gates=65536, reps=10):
     return out
 
 
+def device_ntt_leg(G, dev, d_vec, n, kinds, steps, warmup, barrier):
+    """in-place transforms on a device-resident vector; HIP events on the stream the kernels are launched on"""
+    tstream = torch.cuda.Stream(device=dev)
+    stream = tstream.cuda_stream
+    torch.cuda.synchronize()
+    out = {}
+    for kind in kinds:
+        for _ in range(warmup):
+            G.ntt_device(d_vec.data_ptr(), n, kind, stream=stream)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(tstream)
+        for _ in range(steps):
+            G.ntt_device(d_vec.data_ptr(), n, kind, stream=stream)
+        e1.record(tstream)
+        barrier()
+        wall = (time.perf_counter() - t0) / steps
+        out[kind] = {"ms_per_step": wall * 1e3, "elements_per_s": n / wall, "device_ms": e0.elapsed_time(e1) / steps}
+    return out
+
+
+def ntt_roofline(n, device_ms, traffic):
+    b = 2 * 32 * n  # SURVEY 8d: the vector read once, written once
+    return {"bound": "hbm", "achieved": b / (device_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": "ntt_pass_kernel x2", "algorithmic_bytes": b}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +225,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-window-tables", action="store_true", help="disable the pre-shifted SRS window tables")
     ap.add_argument("--no-plonk", action="store_true", help="skip the BASELINE config 5 leg (resident PLONK prover, 2^16 gates)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (host-pointer, PCIe) legs, the 2^22 transforms and config 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
     args = ap.parse_args()
@@ -161,16 +253,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- synthetic inputs, identical on every rank, resident in HBM before any timed region -------------------------
-    x_secret = random_field_elements(1, 0x5EED)[0]
-    cpu_leg = (rank == 0 and world == 1 and not args.no_cpu_baseline)  # the CPU reference is timed at N = 1 only
-    want_table = cpu_leg
-    if want_table:
+    # ---- synthetic inputs, identical on every rank, resident in HBM before any timed region --------------
+    # scalars: splitmix64 from state 0x9e3779b97f4a7c15, 4 outputs per scalar, limb 3 masked to 60 bits, converted to Montgomery form;
+    # SRS: P_i = x^i G with x = the first scalar of a separately seeded stream
+    x_raw = raw_scalars(1, 0x5EED0F5EC2E7C0DE)[0]
+    x_secret = limbs_of(sum(int(v) << (64 * i) for i, v in enumerate(x_raw)) * (1 << 256) % FR_MODULUS)
+    single = (rank == 0 and world == 1)
+    cpu_leg = single and not args.no_cpu_baseline  # the CPU reference is timed at N = 1 only
+    host_legs = single and not args.no_boundary   # boundary-inclusive legs need the host copy of the point table
+    if cpu_leg or host_legs:
         srs, table = G.srs_generate(x_secret, n, want_host_table=True)
     else:
         srs, table = G.srs_generate(x_secret, n), None
-    scalars = random_field_elements(n, 0xC0FFEE)
-    d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
+    d_scalars = to_montgomery_on_device(G, raw_scalars(n, SPLITMIX_GAMMA), dev)
+    scalars = d_scalars.cpu().numpy().view(np.uint64) if (cpu_leg or host_legs) else None
     W = G.srs_num_windows(srs, n)
     wb, we = W * rank // world, W * (rank + 1) // world
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the 96-byte partial sums are exchanged
@@ -213,9 +309,10 @@ def main():
         return part if world == 1 else exchange.finish(exchange.start(part))
 
     res = run_steps(args.warmup)
-    # live per-kernel timing INSIDE the timed region: the library brackets every stage with HIP events on the stream the
-    # kernels are launched on (two event records per stage; the kernels themselves are unchanged)
-    G.set_timing(True)
+    # live timing of the dominant kernel INSIDE the timed region: the library brackets the accumulation with HIP events on the stream
+    # it is launched on (timing level 2: two markers per MSM; an event after EVERY stage costs 0.085 ms per step in marker latency
+    # on the launch chains and is taken in a separate, untimed pipelined run below)
+    G.set_timing(2)
     stage_log.clear()
     barrier()
     t0 = time.perf_counter()
@@ -223,18 +320,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     G.set_timing(False)
+    acc_pipe = np.mean(np.array(stage_log), axis=0) if stage_log else np.zeros(8)
+    G.set_timing(1)
+    stage_log.clear()
+    run_steps(max(6, args.steps // 2))
+    barrier()
+    G.set_timing(False)
     stage_pipe = np.mean(np.array(stage_log), axis=0) if stage_log else np.zeros(8)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     msm_ms = dt / args.steps * 1e3
-    # latency of one isolated MSM (no pipelining), for the record
-    t0 = time.perf_counter()
-    for _ in range(5):
-        finish(issue())
+    # latency of one isolated MSM (no pipelining): median of 10 after 3
+    msm_latency_ms, msm_latency_min = median_ms(lambda: finish(issue()), 10, 3)
     barrier()
-    msm_latency_ms = (time.perf_counter() - t0) / 5 * 1e3
 
     # window-sharded result == the same MSM done by one rank alone (outside the timed region)
     sharded_ok = None
@@ -254,33 +354,91 @@ def main():
     G.set_timing(False)
 
     # ---- NTT leg (single GPU; every rank runs it so the barrier semantics stay simple, rank 0 reports) ---------------
-    ntt_in = random_field_elements(n, 0xF00D)
+    ntt_in = raw_scalars(n, 0xF00D)
     d_co = torch.from_numpy(ntt_in.view(np.int64)).to(dev)
-    tstream = torch.cuda.Stream(device=dev)  # the NTT kernels are launched on this stream, and so are the timing events
-    stream = tstream.cuda_stream
-    torch.cuda.synchronize()
-    ntt = {}
-    for kind in ("fft", "coset_fft"):
-        for _ in range(args.warmup):
-            G.ntt_device(d_co.data_ptr(), n, kind, stream=stream)
-        barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(tstream)
-        for _ in range(args.steps):
-            G.ntt_device(d_co.data_ptr(), n, kind, stream=stream)
-        e1.record(tstream)
-        barrier()
-        wall = (time.perf_counter() - t0) / args.steps
-        ntt[kind] = {"ms_per_step": wall * 1e3, "elements_per_s": n / wall, "device_ms": e0.elapsed_time(e1) / args.steps}
-    d_chk = torch.from_numpy(ntt_in.view(np.int64)).to(dev)
-    G.ntt_device(d_chk.data_ptr(), n, "fft", stream=stream)
-    torch.cuda.synchronize()
-    ntt_out = d_chk.cpu().numpy().view(np.uint64)
+    ntt = device_ntt_leg(G, dev, d_co, n, ("fft", "coset_fft"), args.steps, args.warmup, barrier)
+    ntt_out = None
+    if cpu_leg:
+        ntt_out = {}
+        for kind in ("fft", "coset_fft"):
+            d_chk = torch.from_numpy(ntt_in.view(np.int64)).to(dev)
+            G.ntt_device(d_chk.data_ptr(), n, kind)
+            torch.cuda.synchronize()
+            ntt_out[kind] = d_chk.cpu().numpy().view(np.uint64)
+
+    # ---- single-GPU extras (rank 0, N = 1): 4 * 2^20 transforms, config 1, the boundary-inclusive numbers ---------------------------
+    ntt22 = ntt22_in = ntt22_out = None
+    config1 = boundary = None
+    table16 = res16 = None
+    if host_legs:
+        n22 = 1 << 22
+        ntt22_in = raw_scalars(n22, 0xBEEF)
+        d22 = torch.from_numpy(ntt22_in.view(np.int64)).to(dev)
+        ntt22 = device_ntt_leg(G, dev, d22, n22, ("fft", "coset_fft"), max(5, args.steps // 2), args.warmup, barrier)
+        if cpu_leg:
+            ntt22_out = {}
+            for kind in ("fft", "coset_fft"):
+                d22.copy_(torch.from_numpy(ntt22_in.view(np.int64)))
+                G.ntt_device(d22.data_ptr(), n22, kind)
+                torch.cuda.synchronize()
+                ntt22_out[kind] = d22.cpu().numpy().view(np.uint64)
+        del d22
+        # config 1 (bench_barretenberg.cpp:308-332): 2^16 points of the same SRS and the first 2^16 scalars
+        m = 1 << 16
+        table16 = np.ascontiguousarray(table[:2 * m])
+        h16 = G.srs_register(table16)
+        lat16, lat16_min = median_ms(lambda: G.msm_device(h16, d_scalars.data_ptr(), m), 10, 3)
+
+        def two_in_flight(k=10):
+            infl = []
+            for _ in range(k):
+                infl.append(G.msm_device_async(h16, d_scalars.data_ptr(), m))
+                if len(infl) == 2:
+                    G.msm_wait(infl.pop(0))
+            while infl:
+                G.msm_wait(infl.pop(0))
+        pipe16, _ = median_ms(two_in_flight, 10, 2)
+        res16 = G.msm_device(h16, d_scalars.data_ptr(), m)
+        config1 = {"workload": "2^16-point G1 MSM (BASELINE config 1 on the GPU), inputs resident", "latency_ms": lat16, "latency_ms_min": lat16_min,
+                   "ms_per_msm_two_in_flight": pipe16 / 10, "points_per_s": m / (pipe16 / 10 * 1e-3)}
+        G.srs_release(h16)
+        # boundary-inclusive: wall-clock around the drop-in calls with pageable host buffers -- H2D of the scalars (SRS
+        # resident, as in the prover), H2D + D2H of the coefficients; median of 10 after 3; different scalars every call
+        hs = [scalars, np.roll(scalars, 1, axis=0).copy(), np.roll(scalars, 2, axis=0).copy()]
+        turn = [0]
+
+        def one_msm():
+            turn[0] += 1
+            return G.pippenger(hs[turn[0] % 3], table, n)
+        b_msm, b_msm_min = median_ms(one_msm, 10, 3)
+        assert np.array_equal(G.pippenger(hs[0], table, n), res), "host-pointer MSM differs from the resident one"
+        b_bat, b_bat_min = median_ms(lambda: G.batched_scalar_multiplications([(table, h, n) for h in hs]), 10, 3)
+        host_co = ntt_in.copy()
+        bn = {}
+        for kind in ("fft", "coset_fft"):
+            def one_ntt():
+                host_co[...] = ntt_in
+                G.ntt(host_co, kind)
+            t_copy, _ = median_ms(lambda: host_co.__setitem__(Ellipsis, ntt_in), 5, 1)
+            t_all, _ = median_ms(one_ntt, 10, 3)
+            bn[kind] = {"ms": t_all - t_copy, "elements_per_s": n / ((t_all - t_copy) * 1e-3)}
+        host22 = ntt22_in.copy()
+
+        def one_ntt22():
+            host22[...] = ntt22_in
+            G.ntt(host22, "fft")
+        t_copy22, _ = median_ms(lambda: host22.__setitem__(Ellipsis, ntt22_in), 5, 1)
+        t22, _ = median_ms(one_ntt22, 10, 3)
+        boundary = {"note": "wall-clock around the C-ABI calls with pageable host buffers, PCIe included; median of 10 after 3 warm-ups; SRS resident (its one-time upload excluded)",
+                    "msm_g1_2e20": {"call": "bbgpu_msm_g1 (pippenger)", "ms": b_msm, "ms_min": b_msm_min, "points_per_s": n / (b_msm * 1e-3), "h2d_bytes": 32 * n},
+                    "msm_g1_batch_3x2e20": {"call": "bbgpu_msm_g1_batch (batched_scalar_multiplications), 3 jobs", "ms_per_msm": b_bat / 3, "ms_per_msm_min": b_bat_min / 3,
+                                            "points_per_s": 3 * n / (b_bat * 1e-3)},
+                    "ntt_2e20": {"call": "bbgpu_ntt (fft / coset_fft)", "fft": bn["fft"], "coset_fft": bn["coset_fft"], "h2d_plus_d2h_bytes": 64 * n},
+                    "ntt_2e22_fft": {"ms": t22 - t_copy22, "elements_per_s": n22 / ((t22 - t_copy22) * 1e-3)}}
 
     # ---- BASELINE config 5 (rank 0 only, reported beside the headline): the resident PLONK prover on a 2^16-gate circuit ----------
     plonk = None
-    if rank == 0 and world == 1 and not args.no_plonk:  # single-GPU leg; the N > 1 runs measure the window-sharded MSM only
+    if single and not args.no_plonk:  # single-GPU leg; the N > 1 runs measure the window-sharded MSM only
         plonk = plonk_leg(G, args)
 
     if rank == 0:
@@ -289,18 +447,27 @@ def main():
         # still runs, so the event pair around it also spans its wait in the queue (stage_pipe[3], kept as kernel_ms_events_raw); it cannot
         # execute before the previous one has drained, so its execution time is the spacing of consecutive end-of-accumulation events
         # when that is shorter (stage_pipe[7], HIP events on the launch streams as well: csrc/msm.hip finish_timing)
-        acc_raw_ms = float(stage_pipe[3]) if stage_pipe[3] > 0 else float(stage[3])
-        acc_ms = float(stage_pipe[7]) if stage_pipe[7] > 0 else acc_raw_ms
+        acc_raw_ms = float(acc_pipe[3]) if acc_pipe[3] > 0 else float(stage[3])
+        acc_ms = float(acc_pipe[7]) if acc_pipe[7] > 0 else acc_raw_ms
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        # HBM bytes per launch from the PMC passes of the SAME binary (profiles/, tools/pmc_summary.py), corrected by the factor the
+        # gather calibration kernel of known traffic gave for this access shape
+        traffic = ntt_traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("msm_accumulate_kernel_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("msm_accumulate_kernel_bytes_per_launch")
+                ntt_traffic = tj.get("ntt_2e20_bytes_per_transform")
             except Exception:
                 traffic = None
-        ntt_bytes = 2 * 32 * n
         share_adds = (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation
+        # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition = 738 v_mad_u64_u32 with two VGPR factors
+        # + 729 with an SGPR factor + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 209 v_and_b32 + ~430 other VALU, priced at the measured
+        # chip-wide issue rates of tools/ubench/ubench_inst (445 / 489 / 565 / 537 / 916 / ~850 G wave-instructions/s): 4.24 ns of chip time per
+        # wave-addition = the floor this instruction stream allows
+        ns_per_wave_add = 738 / 445.0 + 729 / 489.0 + 144 / 565.0 + 81 / 537.0 + 209 / 916.0 + 430 / 850.0
+        issue_floor_ms = share_adds / 64 * ns_per_wave_add * 1e-6
         line = {
             "metric": "BN254 G1 MSM points/sec at n=2^%d (Fr NTT elems/sec in 'ntt')" % args.log2n,
             "value": n / (msm_ms * 1e-3),
@@ -310,12 +477,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": msm_ms,
             "latency_ms_single_msm": msm_latency_ms,
+            "latency_ms_single_msm_min": msm_latency_min,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32x9 (256-bit Montgomery, 29-bit limbs)",
             "data": "synthetic",
-            "config": {"workload": "2^%d-point BN254 G1 MSM, uniformly random 253-bit scalars vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
+            "config": {"workload": "2^%d-point BN254 G1 MSM, splitmix64 scalars (< 2^252, Montgomery form) vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
                        "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
                        "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
@@ -324,32 +492,40 @@ def main():
             "stage_ms_in_timed_region": {"device_total": float(stage_pipe[0]), "digits": float(stage_pipe[1]), "sort": float(stage_pipe[2]),
                                          "accumulate": float(stage_pipe[3]), "merge": float(stage_pipe[4]), "bucket_folds": float(stage_pipe[5]),
                                          "slices_collect": float(stage_pipe[6]),
-                                         "note": "two MSMs in flight: stages of consecutive steps overlap, so they sum to more than ms_per_step"},
+                                         "note": "two MSMs in flight, a separate run after the timed region with an event after every stage: stages of consecutive steps overlap, so they sum to more than ms_per_step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "msm_accumulate_kernel", "kernel_ms": acc_ms, "kernel_ms_events_raw": acc_raw_ms, "kernel_ms_alone": float(stage[3]),
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes,
-                         # the bound that does apply: one mixed XYZZ addition per (point, window) = 1,467 v_mad_u64_u32 per lane,
-                         # against the chip's measured issue rate for that instruction (470 G wave-instructions/s)
-                         "valu": {"bound": "v_mad_u64_u32 issue", "achieved": share_adds * 1467 / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0,
-                                  "peak": 470e9 * 64 / 1e12, "unit": "T lane-mad/s",
-                                  "frac": (share_adds * 1467 / (acc_ms * 1e-3)) / (470e9 * 64) if acc_ms > 0 else 0.0}},
+                         "valu": {"bound": "VALU instruction issue of the mixed addition's instruction stream at the measured per-instruction rates",
+                                  "floor_ms": issue_floor_ms, "achieved_ms": acc_ms, "frac": issue_floor_ms / acc_ms if acc_ms > 0 else 0.0,
+                                  "mad_only": {"achieved": share_adds * 1467 / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0, "peak": 467e9 * 64 / 1e12,
+                                               "unit": "T lane-mad/s", "frac": (share_adds * 1467 / (acc_ms * 1e-3)) / (467e9 * 64) if acc_ms > 0 else 0.0}}},
             "ntt": {"metric": "Fr radix-2 NTT elements/s at n=2^%d, in place on a device-resident vector" % args.log2n,
-                    "fft": ntt["fft"], "coset_fft": ntt["coset_fft"],
-                    "roofline": {"bound": "hbm", "achieved": ntt_bytes / (ntt["fft"]["device_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ntt_bytes / (ntt["fft"]["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                 "kernel": "ntt_pass_kernel x2"}},
+                    "fft": ntt["fft"], "coset_fft": ntt["coset_fft"], "roofline": ntt_roofline(n, ntt["fft"]["device_ms"], ntt_traffic)},
         }
+        if ntt22 is not None:
+            line["ntt_2e22"] = {"metric": "Fr radix-2 NTT elements/s at n=4*2^20 (BASELINE config 3)", "fft": ntt22["fft"], "coset_fft": ntt22["coset_fft"],
+                                "roofline": ntt_roofline(1 << 22, ntt22["fft"]["device_ms"], None)}
+        if config1 is not None:
+            line["config1_2e16"] = config1
+        if boundary is not None:
+            line["boundary"] = boundary
         if sharded_ok is not None:
             line["sharded_result_equals_single_gpu"] = sharded_ok
         if plonk is not None:
             line["plonk"] = plonk
         if cpu_leg:
-            # expected NTT output comes from the reference run inside cpu_baseline; pass the GPU's so it can compare
-            cb = cpu_baseline(table, scalars, res[:8], ntt_in, ntt_out)
+            # expected outputs come from the reference run inside cpu_baseline; pass the GPU's so it can compare
+            cb = cpu_baseline(table, scalars, res[:8], ntt_in, ntt_out, table16 if table16 is not None else table[:2 << 16],
+                              res16[:8] if res16 is not None else G.msm_device(srs, d_scalars.data_ptr(), 1 << 16)[:8], ntt22_in if ntt22_in is not None else raw_scalars(1 << 22, 0xBEEF), ntt22_out)
             line["cpu_baseline"] = cb
-            line["speedup_vs_cpu_all_cores"] = line["value"] / cb["value"]
+            # what a drop-in caller sees (boundary-inclusive, one call at a time) against the reference's wall time for the same call
+            if boundary is not None and "all_cores_ms" in cb:
+                line["speedup_vs_cpu_all_cores"] = cb["all_cores_ms"] / boundary["msm_g1_2e20"]["ms"]
+                line["speedup_vs_cpu_1_thread"] = cb["single_thread_ms"] / boundary["msm_g1_2e20"]["ms"]
+            line["speedup_vs_cpu_all_cores_resident_pipelined"] = line["value"] / cb["value"]
             if "single_thread_value" in cb:
-                line["speedup_vs_cpu_1_thread"] = line["value"] / cb["single_thread_value"]
+                line["speedup_vs_cpu_1_thread_resident_pipelined"] = line["value"] / cb["single_thread_value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

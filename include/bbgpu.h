@@ -97,6 +97,11 @@ int bbgpu_srs_cache_stats(int* live_entries, int* auto_entries, uint64_t* auto_b
  * generate_pippenger_point_table -- the `monomials` array of ReferenceString (reference_string.cpp:16-35) -- ready for
  * bbgpu_srs_register.  Host code; needs no GPU. */
 int bbgpu_transcript_read_g1(const char* path, size_t degree, uint64_t* points_endo_table_out);
+/* The writer of the same format: the file io::read_transcript(monomials, g2_x, degree, path) accepts for the SRS whose endo table is
+ * given -- degree - 1 G1 points (the generator is implicit), then G2 and x * G2 (the verifier's pairing input, io.hpp:171-180) computed
+ * here from the secret `x_mont` (Montgomery), then the 64-byte checksum slot the reference never verifies.  Together with
+ * bbgpu_srs_generate this stands in for the missing srs_db/transcript.dat of BASELINE configs 2 and 5.  Host code; needs no GPU. */
+int bbgpu_transcript_write(const char* path, const uint64_t* points_endo_table, size_t degree, const uint64_t x_mont[4]);
 /* device-side generation of the synthetic SRS x^i * G, i < n, straight into a resident table; optionally also written
  * back to the host as the reference-format 2n endo table (may be NULL).  Stands in for the missing srs_db/transcript.dat */
 int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out);
@@ -108,7 +113,7 @@ int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, siz
  * (verifier.cpp:359-363) and proofs of n = 4 circuits (test_verifier.cpp:105-122).  Host-pointer MSMs of at most `msm_max_points`
  * points against a table that is not resident, and host-buffer transforms (bbgpu_ntt) of at most `ntt_max_elements` (<= 64)
  * elements, are answered on the host by csrc/host_small.hpp -- no device allocation, copy or launch; results identical.  Defaults
- * 32 / 16 (env BBGPU_HOST_MSM_MAX / BBGPU_HOST_NTT_MAX); 0 / 0 sends every size to the GPU.  Nothing larger ever runs on the host. */
+ * 24 / 16 (env BBGPU_HOST_MSM_MAX / BBGPU_HOST_NTT_MAX); 0 / 0 sends every size to the GPU.  Nothing larger ever runs on the host. */
 void bbgpu_set_host_thresholds(int msm_max_points, int ntt_max_elements);
 
 /* drop-in for scalar_multiplication::batched_scalar_multiplications(mul_state, num) (:650-772); layout-identical to
@@ -270,7 +275,8 @@ int bbgpu_selftest_g1(int op, const uint64_t* p, const uint64_t* q, size_t n, ui
  * with hipEvents on the stream the kernels ran on.  index: 0 = total, then per stage: 1 digits, 2 sort, 3 accumulation,
  * 4 merge, 5 row/column sums, 6 final sums, 7 accumulation without the time it sat queued behind the previous MSM's accumulation. */
 int bbgpu_last_timing(float* ms_out, int max_entries);
-void bbgpu_set_timing(int enabled);
+void bbgpu_set_timing(int level); /* 0 off; 1 an event after every stage (adds ~0.08 ms of marker latency to a pipelined 2^20 step); 2 only
+                                     the pair around the accumulation (indices 3 and 7 are filled): what bench.py's timed region uses */
 
 #ifdef __cplusplus
 }

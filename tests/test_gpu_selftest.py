@@ -47,8 +47,12 @@ def test_device_field_ops_vs_reference_outputs(gpu, golden, field):
     b = np.stack([limbs(c["b"]) for c in cases])
     for op in ("mul", "sqr", "add", "sub", "neg"):
         got = _ints(gpu.selftest_field(field, op, a, b))
+        hits = 0
         for c, g in zip(cases, got):
-            assert g == to_int(limbs(c[op])) % p and g < p, (field, op, c["a"])
+            if op in c:  # not every case carries every op
+                assert g == to_int(limbs(c[op])) % p and g < p, (field, op, c["a"])
+                hits += 1
+        assert hits >= 4, (field, op)
 
 
 @pytest.mark.parametrize("field", ["fq", "fr"])
@@ -122,6 +126,7 @@ def test_device_g1_ops_vs_reference_outputs(gpu, oracle, golden):
     cases = golden("g1_ops.json")["cases"]
     acc = np.stack([limbs(c["acc"]) for c in cases])
     q = np.stack([limbs(c["scalar_mul_G"]) for c in cases])
+    q[:, 8:12] = 0  # the mixed addition reads affine x, y; bit 0 of z limb 0 is its "negate" flag
     m = np.stack([limbs(c["mixed_add"]) for c in cases])
     a = np.stack([limbs(c["add"]) for c in cases])
     for op, p_in, q_in, key in (("madd", acc, q, "mixed_add"), ("add", m, acc, "add"), ("dbl", a, a, "dbl")):

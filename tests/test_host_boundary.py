@@ -215,3 +215,29 @@ def test_shim_covers_the_replaced_translation_units():
     for m in missing:
         assert any(a in m for a in allowed), m
     assert len(externs(sm) & shim) >= 6
+
+
+def test_transcript_writer_matches_the_reference_writer(lib, oracle, tmp_path):
+    """bbgpu_transcript_write (io.hpp:36-182 restated for writing, G2 half computed by csrc/host_g2.hpp) against the file the
+    REFERENCE's own code wrote for the same secret (oracle/_ref/transcript.dat <- g1/g2::group_exponentiation in plonk_cpu): the G1
+    bytes of the shared prefix and both G2 points -- x * G2 is the verifier's pairing input -- must be identical; and our reader
+    reads our file back."""
+    from oracle.pyoracle import FR
+    ref_file = os.path.join(ROOT, "oracle", "_ref", "transcript.dat")
+    if not os.path.exists(ref_file):
+        pytest.skip("reference-written transcript not built here")
+    secret_raw = np.array([0x0123456789abcdef, 0xfedcba9876543210, 0x0f1e2d3c4b5a6978, 0x0123456789abcdef], dtype=np.uint64)  # oracle/plonk_driver.cpp secret()
+    x = oracle.to_mont(FR, secret_raw)
+    degree = 1025
+    table = oracle.point_table(oracle.make_srs(x, degree))
+    path = str(tmp_path / "transcript.dat")
+    lib.write_transcript(path, table, degree, x)
+    ours, ref = open(path, "rb").read(), open(ref_file, "rb").read()
+    assert len(ours) == 28 + 64 * (degree - 1) + 256 + 64
+    num_ref = int.from_bytes(ref[16:20], "big")
+    assert int.from_bytes(ours[16:20], "big") == degree - 1 and int.from_bytes(ours[8:12], "big") == degree - 1
+    assert ours[0:8] == ref[0:8] and ours[12:16] == ref[12:16] and ours[20:28] == ref[20:28]  # numbers / G2 counts / start_from
+    assert ours[28:28 + 64 * (degree - 1)] == ref[28:28 + 64 * (degree - 1)]                   # x G .. x^1024 G
+    g2_ours, g2_ref = ours[28 + 64 * (degree - 1):][:256], ref[28 + 64 * num_ref:][:256]
+    assert g2_ours == g2_ref                                                                   # G2, x G2
+    assert np.array_equal(lib.read_transcript(path, degree), table)

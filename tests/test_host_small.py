@@ -11,7 +11,9 @@ from tests.util import CONST_SEED, NTT_SEED, SCALAR_SEED, limbs, noncanonical, s
 @pytest.fixture(scope="module")
 def lib():
     from barretenberg_amd import BbGpu
-    return BbGpu(init=False)  # never binds a device: everything below must be answered on the host
+    g = BbGpu(init=False)  # never binds a device: everything below must be answered on the host
+    g.set_host_thresholds(32, 16)  # the host code is exercised up to 32 points here (the shipped default is 24: the measured crossover)
+    return g
 
 
 @pytest.fixture(scope="module")

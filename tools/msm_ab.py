@@ -25,10 +25,10 @@ for lg in (20, 16):
             while infl:
                 G.msm_wait(infl.pop(0))
         out = []
-        for depth in (1, 2):
+        for depth in (1, 2, 3):
             run(4, depth); torch.cuda.synchronize()
             best = 1e9
             for _ in range(3):
                 t0 = time.perf_counter(); run(20, depth); best = min(best, (time.perf_counter() - t0) / 20)
             out.append(best * 1e3)
-        print("2^%d, %2d of %d windows: latency %.4f ms, two in flight %.4f ms/step" % (lg, we, W, out[0], out[1]), flush=True)
+        print("2^%d, %2d of %d windows: latency %.4f ms, two in flight %.4f ms/step, three in flight %.4f ms/step" % (lg, we, W, out[0], out[1], out[2]), flush=True)
