@@ -518,9 +518,17 @@ __device__ __forceinline__ void load_raw(Xyzz& p, const uint32_t* src)
         p.zzz.d[i] = src[3 * NL + i];
     }
 }
+// Register budget of the accumulation: with the asm products the allocator settles at 132 VGPRs (three waves per SIMD, which is what the
+// LDS reservation admits anyway).  Holding it to 128 like the tail kernels (-DBBGPU_ACC_CAP128: 4 spills, one scratch access in the hot
+// loop) was measured in one box at 1.272 vs 1.259 ms per pipelined 2^20 step: no gain, the default stays uncapped.
+#ifdef BBGPU_ACC_CAP128
+#define ACC_VGPR_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define ACC_VGPR_CAP
+#endif
 constexpr int RAW_WORDS = 4 * NL; // 36 words per partial: lazy limbs, no canonicalisation on the hot path
 
-__global__ void __launch_bounds__(MSM_THREADS) msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ gstart, uint32_t* __restrict__ partials,
                                                                    uint32_t total_buckets, uint32_t ch, uint32_t prio)
 {

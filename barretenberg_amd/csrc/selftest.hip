@@ -121,7 +121,7 @@ __device__ void st_xyzz(uint64_t* o, const Xyzz& p)
     for (int i = 0; i < 16; i++) o[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
 }
 
-// p_in: n x 12 limbs (Jacobian), q_in: n x 12 limbs (Jacobian; the mixed addition reads its affine x, y and the negate flag in z limb 0 bit 0)
+// p_in: n x 12 limbs (Jacobian), q_in: n x 12 limbs (Jacobian; the mixed addition reads only its affine x, y)
 __global__ void selftest_g1_kernel(const uint64_t* p_in, const uint64_t* q_in, uint64_t* out, int n, int op)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,12 +129,13 @@ __global__ void selftest_g1_kernel(const uint64_t* p_in, const uint64_t* q_in, u
     Xyzz P, Q, R;
     ld_jacobian(P, p_in + 12 * i);
     switch (op) {
-    case BBGPU_SELFTEST_G1_MADD: { // g1::mixed_add (group.hpp:219-322), the MSM's hot operation, with its conditional negation
+    case BBGPU_SELFTEST_G1_MADD:       // g1::mixed_add (group.hpp:219-322), the MSM's hot operation,
+    case BBGPU_SELFTEST_G1_MADD_NEG: { // and with its conditional negation of the affine operand (group_impl_asm.tcc:71-153) taken
         AffineV<2> a;
         a.x = m256_to_m261<Fq>(ld<Fq>(q_in + 12 * i));
         a.y = m256_to_m261<Fq>(ld<Fq>(q_in + 12 * i + 4));
         R = P;
-        madd(R, cond_neg_affine(a, (q_in[12 * i + 8] & 1) != 0));
+        madd(R, cond_neg_affine(a, op == BBGPU_SELFTEST_G1_MADD_NEG));
         break;
     }
     case BBGPU_SELFTEST_G1_ADD: // g1::add (:324-448)

@@ -126,7 +126,6 @@ def test_device_g1_ops_vs_reference_outputs(gpu, oracle, golden):
     cases = golden("g1_ops.json")["cases"]
     acc = np.stack([limbs(c["acc"]) for c in cases])
     q = np.stack([limbs(c["scalar_mul_G"]) for c in cases])
-    q[:, 8:12] = 0  # the mixed addition reads affine x, y; bit 0 of z limb 0 is its "negate" flag
     m = np.stack([limbs(c["mixed_add"]) for c in cases])
     a = np.stack([limbs(c["add"]) for c in cases])
     for op, p_in, q_in, key in (("madd", acc, q, "mixed_add"), ("add", m, acc, "add"), ("dbl", a, a, "dbl")):
@@ -172,31 +171,23 @@ def test_device_g1_exceptional_cases(gpu, oracle, golden):
         n = a.copy()
         n[4:8] = oracle.neg(FQ, a[4:8])
         neg.append(n)
-    flag = np.zeros(12, dtype=np.uint64)
-    flag[8] = 1  # "negate q" flag of the mixed addition
     P, A, N = np.stack(jac), np.stack(aff), np.stack(neg)
     want_dbl = [oracle.g1_normalize(oracle.g1_dbl(j)) for j in jac]
-    # mixed addition: P + P -> doubling branch; P + (-P) -> infinity (both via a negated y and via the negate flag); inf + Q -> Q
+    # mixed addition: P + P -> doubling branch; P + (-P) -> infinity (both via a negated y and via the negating entry); inf + Q -> Q
     for r, w in zip(gpu.selftest_g1("madd", P, A), want_dbl):
         assert np.array_equal(_norm_xyzz(oracle, r), w)
     for r in gpu.selftest_g1("madd", P, N):
         assert np.array_equal(_norm_xyzz(oracle, r), _inf())
-    Aflag = A.copy()
-    Aflag[:, 8:12] = flag[8:12]
-    for r in gpu.selftest_g1("madd", P, Aflag):
+    for r in gpu.selftest_g1("madd_neg", P, A):
         assert np.array_equal(_norm_xyzz(oracle, r), _inf())
-    Nflag = N.copy()
-    Nflag[:, 8:12] = flag[8:12]
-    for r, w in zip(gpu.selftest_g1("madd", P, Nflag), want_dbl):  # P + -(-P)
+    for r, w in zip(gpu.selftest_g1("madd_neg", P, N), want_dbl):  # P - (-P)
         assert np.array_equal(_norm_xyzz(oracle, r), w)
     INF = np.stack([_inf()] * len(jac))
     for r, a in zip(gpu.selftest_g1("madd", INF, A), aff):
         assert np.array_equal(_norm_xyzz(oracle, r), a)
     # mixed addition of two different points, negated: P_i - Q_{i+1}
     Q = np.roll(A, 1, axis=0)
-    Qf = Q.copy()
-    Qf[:, 8:12] = flag[8:12]
-    for r, j, n in zip(gpu.selftest_g1("madd", P, Qf), jac, np.roll(N, 1, axis=0)):
+    for r, j, n in zip(gpu.selftest_g1("madd_neg", P, Q), jac, np.roll(N, 1, axis=0)):
         assert np.array_equal(_norm_xyzz(oracle, r), oracle.g1_normalize(oracle.g1_mixed_add(j, n[:8])))
     # full addition: P + P, P + (-P), inf + P, P + inf, inf + inf
     for r, w in zip(gpu.selftest_g1("add", P, A), want_dbl):

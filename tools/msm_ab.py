@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""one-box A/B helper: single-MSM latency, two-in-flight step time at the full and at the 1/8 window share, 2^16 latency, prover 2^16"""
+"""one-box A/B helper (medians of 5 x 20 steps): single-MSM latency, two-in-flight step time at the full and at the 1/8 window share, 2^16 latency, prover 2^16"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,9 +26,9 @@ for lg in (20, 16):
                 G.msm_wait(infl.pop(0))
         out = []
         for depth in (1, 2, 3):
-            run(4, depth); torch.cuda.synchronize()
-            best = 1e9
-            for _ in range(3):
-                t0 = time.perf_counter(); run(20, depth); best = min(best, (time.perf_counter() - t0) / 20)
-            out.append(best * 1e3)
+            run(40 if lg == 20 and we == W else 20, depth); torch.cuda.synchronize()  # the first ~50 ms after idle run ~4 % slow (clock ramp)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); run(20, depth); ts.append((time.perf_counter() - t0) / 20)
+            out.append(float(np.median(ts)) * 1e3)
         print("2^%d, %2d of %d windows: latency %.4f ms, two in flight %.4f ms/step, three in flight %.4f ms/step" % (lg, we, W, out[0], out[1], out[2]), flush=True)
