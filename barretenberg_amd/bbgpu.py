@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_transcript_write", "bbgpu_msm_g1",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
-    "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_selftest_field", "bbgpu_selftest_g1",
+    "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_set_table_share", "bbgpu_selftest_field", "bbgpu_selftest_g1",
     "bbgpu_set_timing",
     "bbgpu_fr_evaluate_device", "bbgpu_fr_batch_invert_device", "bbgpu_fr_product_scan_device", "bbgpu_fr_mul_device",
     "bbgpu_kate_opening_device", "bbgpu_lagrange_l1_fft_device", "bbgpu_divide_by_pseudo_vanishing_device",
@@ -250,6 +250,10 @@ class BbGpu:
     def set_host_thresholds(self, msm_max_points, ntt_max_elements):
         """SURVEY 8b small sizes: host-pointer MSMs / transforms up to these sizes are answered on the host (0, 0: everything on the GPU)"""
         self.lib.bbgpu_set_host_thresholds(int(msm_max_points), int(ntt_max_elements))
+
+    def set_table_share(self, rank, world):
+        """tables registered from now on keep only the digit windows rank `rank` of `world` touches (multi-GPU row split); (0, 1): full tables"""
+        self.lib.bbgpu_set_table_share(int(rank), int(world))
 
     def set_precompute(self, on=True):
         self.lib.bbgpu_set_precompute(1 if on else 0)

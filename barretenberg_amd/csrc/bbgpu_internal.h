@@ -51,7 +51,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
 int msm_issue_rows(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n,
                    uint64_t row_begin, uint64_t row_end, hipStream_t st, int want_timing);
 int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing);
-int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uint32_t** d_tab_out, hipStream_t st);
+int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, int w_begin, int w_end, uint32_t** d_alloc_out, uint32_t** d_tab_out, hipStream_t st);
 int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st);
 int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);

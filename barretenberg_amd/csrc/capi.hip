@@ -35,8 +35,9 @@ struct SrsEntry {
     size_t n;
     uint32_t* d_srs;
     bool live;
-    uint32_t* d_tab = nullptr; // pre-shifted window tables [tab_W][n], or null
-    int tab_c = 0, tab_W = 0;
+    uint32_t* d_tab = nullptr; // pre-shifted window tables [tab_W][n], or null: the address window 0 has (or would have)
+    uint32_t* d_tab_alloc = nullptr; // the allocation itself: starts at window tab_wb when only a share of the windows is kept
+    int tab_c = 0, tab_W = 0, tab_wb = 0, tab_we = 0; // windows [tab_wb, tab_we) are resident
     // Address-keyed lookups are only trusted after a CONTENT check: one 64-bit hash per base point (the even table entry the kernels
     // read), taken when the table was uploaded.  A lookup re-hashes the first, the last and up to 14 evenly spaced rows of the range
     // the caller passed (it never touches host memory outside that range: the old table may have been freed) and compares.
@@ -81,6 +82,7 @@ struct Context {
     int host_msm_max = 24;
     int host_ntt_max = 16;
     bool host_env_read = false;
+    int share_rank = 0, share_world = 1; // window share of the tables built from now on (bbgpu_set_table_share)
     // Workspaces shared by every caller (NTT scratch, polynomial temporaries): users on different streams are chained by this event
     hipEvent_t shared_done = nullptr;
     hipStream_t shared_last = nullptr;
@@ -162,8 +164,8 @@ void free_entry(SrsEntry& e)
     // an asynchronous MSM may still be reading the table: drain the device first (rare path)
     (void)hipDeviceSynchronize();
     if (e.d_srs) (void)hipFree(e.d_srs);
-    if (e.d_tab) (void)hipFree(e.d_tab);
-    e.d_srs = e.d_tab = nullptr;
+    if (e.d_tab_alloc) (void)hipFree(e.d_tab_alloc);
+    e.d_srs = e.d_tab = e.d_tab_alloc = nullptr;
     e.live = false;
     e.row_hash.clear();
     e.row_hash.shrink_to_fit();
@@ -202,7 +204,10 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
     if (const char* ev = getenv("BBGPU_TABLE_C")) c = std::min(17, std::max(4, atoi(ev))); // tuning knob: window size of the tables
     const int W = msm_num_windows(c);
     const bool want_tab = g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24);
-    e.bytes = n * 64 + (want_tab ? (size_t)W * n * 64 : 0);
+    // a rank of an N-way row split touches windows [floor(W r / N), ceil(W (r + 1) / N)) only (bbgpu_set_table_share)
+    const int twb = (int)((int64_t)W * g_ctx.share_rank / g_ctx.share_world);
+    const int twe = (int)(((int64_t)W * (g_ctx.share_rank + 1) + g_ctx.share_world - 1) / g_ctx.share_world);
+    e.bytes = n * 64 + (want_tab ? (size_t)(twe - twb) * n * 64 : 0);
     if (auto_registered) {
         for (auto& o : g_ctx.srs)
             if (o.live && o.auto_registered && o.host_ptr && host_ptr && ranges_overlap(o, host_ptr, n)) free_entry(o);
@@ -219,13 +224,15 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
         }
     }
     if (want_tab) {
-        int rc = srs_build_table(d_srs, n, c, W, &e.d_tab, g_ctx.stream);
+        int rc = srs_build_table(d_srs, n, c, W, twb, twe, &e.d_tab_alloc, &e.d_tab, g_ctx.stream);
         if (rc) {
             (void)hipFree(d_srs);
             return rc;
         }
         e.tab_c = c;
         e.tab_W = W;
+        e.tab_wb = twb;
+        e.tab_we = twe;
     }
     g_ctx.srs.push_back(std::move(e));
     return (int)g_ctx.srs.size() - 1;
@@ -234,8 +241,15 @@ int entry_windows(const SrsEntry& e, size_t n)
 {
     return e.d_tab ? e.tab_W : msm_num_windows(msm_choose_c(n ? n : 1));
 }
+bool windows_resident(const SrsEntry& e, int wb, int we)
+{
+    if (!e.d_tab || (wb >= e.tab_wb && we <= e.tab_we)) return true;
+    set_error("windows [%d, %d) requested, this table keeps [%d, %d) of %d (bbgpu_set_table_share)", wb, we, e.tab_wb, e.tab_we, e.tab_W);
+    return false;
+}
 int issue_on_entry(MsmSlot& S, const SrsEntry& e, size_t off, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st)
 {
+    if (!windows_resident(e, wb, we)) return BBGPU_ERR_STATE;
     return msm_issue(S, e.d_srs + off * 16, e.d_tab ? e.d_tab + off * 16 : nullptr, e.n, e.tab_c, d_scalars, n, wb, we, st, g_ctx.timing);
 }
 
@@ -388,7 +402,7 @@ void bbgpu_shutdown(void)
     g_ctx.poly_tmp_cap = 0;
     for (auto& e : g_ctx.srs) {
         if (e.live && e.d_srs) (void)hipFree(e.d_srs);
-        if (e.live && e.d_tab) (void)hipFree(e.d_tab);
+        if (e.live && e.d_tab_alloc) (void)hipFree(e.d_tab_alloc);
     }
     g_ctx.srs.clear();
     for (auto& sl : g_ctx.slot) sl.release();
@@ -896,6 +910,16 @@ int bbgpu_srs_num_windows(int srs_handle, size_t n)
     if (srs_handle < 0 || srs_handle >= (int)g_ctx.srs.size() || !g_ctx.srs[srs_handle].live) return BBGPU_ERR_ARG;
     return entry_windows(g_ctx.srs[srs_handle], n);
 }
+// Multi-GPU: rank `rank` of `world` will only ever be asked for its 1/world share of the (window, point) rows of tables registered
+// from now on, so only the digit windows that share touches are built and kept: 15 x 64 MiB at n = 2^20 become ceil(15 / world) + 1 windows.
+void bbgpu_set_table_share(int rank, int world)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (world < 1 || rank < 0 || rank >= world) { rank = 0; world = 1; }
+    g_ctx.share_rank = rank;
+    g_ctx.share_world = world;
+}
+
 void bbgpu_set_precompute(int enabled)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -1060,6 +1084,7 @@ int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
+    if (n && row_end > row_begin && !windows_resident(e, (int)(row_begin / n), (int)((row_end + n - 1) / n))) return BBGPU_ERR_STATE;
     rc = msm_issue_rows(S, e.d_srs + offset * 16, e.d_tab + offset * 16, e.n, e.tab_c, d_scalars, n, row_begin, row_end, st, g_ctx.timing);
     if (rc == BBGPU_ERR_ARG) set_error("bad row range [%llu, %llu) of %d x %zu", (unsigned long long)row_begin, (unsigned long long)row_end, e.tab_W, n);
     if (rc) return rc;
@@ -1096,6 +1121,7 @@ int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
+    if (!windows_resident(e, 0, entry_windows(e, n))) return BBGPU_ERR_STATE;
     rc = msm_issue_batch(S, e.d_srs + offset * 16, e.d_tab ? e.d_tab + offset * 16 : nullptr, e.n, e.tab_c, d_scalars, jobs, n, 0, entry_windows(e, n), st,
                          g_ctx.timing);
     if (rc) return rc;

@@ -149,14 +149,16 @@ __global__ void srs_export_kernel(const uint32_t* __restrict__ srs, uint32_t* __
 // (the reference's generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129, built on the device).
 // One lane per base point: off[w] - off[w-1] doublings per window, one inversion per stored point.  Once per SRS.
 
+// Only windows [w_begin, w_end) are stored (and inverted): a rank of an N-way split keeps 1/N of the table; `tab` is the address window 0 WOULD
+// have (the allocation starts at window w_begin), so every consumer indexes tab[w * n + i] unchanged.
 __global__ void __launch_bounds__(MSM_THREADS) srs_table_kernel(const uint32_t* __restrict__ srs, uint32_t* __restrict__ tab, uint32_t n, WinLayout LO,
-                                                              uint32_t num_windows)
+                                                              uint32_t num_windows, uint32_t w_begin, uint32_t w_end)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t w16[16];
     ld16(srs + (size_t)i * 16, w16);
-    {
+    if (w_begin == 0) {
         uint4* q = reinterpret_cast<uint4*>(tab + (size_t)i * 16);
 #pragma unroll
         for (int t = 0; t < 4; t++) q[t] = make_uint4(w16[4 * t], w16[4 * t + 1], w16[4 * t + 2], w16[4 * t + 3]);
@@ -165,12 +167,13 @@ __global__ void __launch_bounds__(MSM_THREADS) srs_table_kernel(const uint32_t* 
     load_affine_m261(p, w16);
     Xyzz acc;
     from_affine(acc, p);
-    for (uint32_t w = 1; w < num_windows; w++) {
+    for (uint32_t w = 1; w < num_windows && w < w_end; w++) {
         for (uint32_t k = LO.off[w - 1]; k < LO.off[w]; k++) {
             Xyzz t;
             dbl(t, acc);
             acc = t;
         }
+        if (w < w_begin) continue;
         // 2^(c w) P is never infinity: the group order is an odd prime
         const uint64_t e[4] = { Fq::P64[0] - 2, Fq::P64[1], Fq::P64[2], Fq::P64[3] };
         auto inv = pow_u256<Fq>(mul(acc.zz, acc.zzz), e);
@@ -1223,13 +1226,17 @@ int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, 
 }
 
 // builds the pre-shifted window tables for a resident SRS of n points: W x n x 64 bytes
-int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, uint32_t** d_tab_out, hipStream_t st)
+// windows [w_begin, w_end) only; *d_alloc_out is what hipFree takes, *d_tab_out the (virtual) address of window 0
+int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, int w_begin, int w_end, uint32_t** d_alloc_out, uint32_t** d_tab_out, hipStream_t st)
 {
-    uint32_t* d_tab = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tab, (size_t)num_windows * n * 64));
-    srs_table_kernel<<<(uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(d_srs, d_tab, (uint32_t)n, make_layout(c, true), (uint32_t)num_windows);
+    uint32_t* d_alloc = nullptr;
+    HIPCHK(hipMalloc((void**)&d_alloc, (size_t)(w_end - w_begin) * n * 64));
+    uint32_t* d_tab = d_alloc - (size_t)w_begin * n * 16;
+    srs_table_kernel<<<(uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(d_srs, d_tab, (uint32_t)n, make_layout(c, true), (uint32_t)num_windows,
+                                                                                          (uint32_t)w_begin, (uint32_t)w_end);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    *d_alloc_out = d_alloc;
     *d_tab_out = d_tab;
     return BBGPU_OK;
 }

@@ -18,6 +18,7 @@
 // the integer VALU rate, not HBM: (n/2) log2 n + ~2n multiplies at ~1.4e11 mul/s.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <stdint.h>
 #include <stdio.h>
@@ -103,6 +104,8 @@ struct NttPassArgs {
     uint32_t out_sa, out_sb;  // result (k, b) is written to out[k * out_sa + b * out_sb]
     uint32_t lo_bits;         // split of the two-level tables
     uint32_t b_fast;          // 1: consecutive threads walk b first (column pass), 0: a first (row pass)
+    uint32_t half_tile;       // host: launch the 256-thread instance (tiles of 1024 elements)
+    uint32_t store_b_fast;    // fused kernel: the same choice for the STORE (1 when the b index is the contiguous one on the output side)
     uint32_t debug_skip;      // timing experiments only (BBGPU_NTT_SKIP): 1 = skip stages, 2 = skip twist/post multiplies
     uint32_t xcd_remap;       // 1: contiguous tile range per XCD (see ntt_pass_kernel)
     uint32_t batch;           // transforms in this launch (blockIdx.y): transform j works on in + j * in_bstride -> out + j * out_bstride
@@ -277,6 +280,213 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass with its first and last LDS round trips removed (sub-transforms of 16 points and more):
+//   A  load + FIRST stage pair: a thread loads the four rows t, t + S/4, t + S/2, t + 3S/4 of a column (consecutive threads take
+//      consecutive rows / columns: coalesced), runs the radix-2^2 group they form after bit reversal -- group bitrev(t) -- in registers
+//      and only then writes LDS: no separate load phase, the butterflies of one wave run under the loads of the next;
+//   B  the middle stage pairs in LDS as before;
+//   C  LAST stage pair (or the odd last stage) + store: its four outputs j, j + S/4, j + S/2, j + 3S/4 are natural-order rows, so they go
+//      through twist / scaling / canonicalisation straight to memory.
+// Two barriers and two LDS round trips fewer per pass, and the memory phases are no longer pure waiting (all workgroups of a 2^20
+// transform run in lockstep -- one resident wave of them holds the whole vector -- so nothing else could overlap them).
+template <int FLAGS> __device__ __forceinline__ void ntt_finish_store(const NttPassArgs& A, const FrL& x, uint32_t k, uint32_t b)
+{
+    const size_t gidx = (size_t)k * A.out_sa + (size_t)b * A.out_sb;
+    uint32_t w[8];
+    if ((A.debug_skip & 2) != 0) {
+        pack(assume_bound<1, 2>(x), w);
+    } else if constexpr (FLAGS & 2) {
+        const uint32_t ex = b * k; // < n
+        auto tw = mul(load_tw(A.twist_lo, ex & ((1u << A.lo_bits) - 1)), load_tw(A.twist_hi, ex >> A.lo_bits));
+        auto r = mul(x, tw); // 48 * 2 / 169 + 2 = 2  -> fits 256 bits
+        pack(r, w);
+    } else {
+        Fe<Fr, 1, 3> r;
+        if constexpr ((FLAGS & 4) && (FLAGS & 8)) {
+            const uint32_t i = (uint32_t)gidx + blockIdx.y * A.nat_bstep;
+            auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
+            r = mul(mul(x, g), fe_from<Fr>(A.post_const));
+        } else if constexpr (FLAGS & 4) {
+            const uint32_t i = (uint32_t)gidx + blockIdx.y * A.nat_bstep;
+            auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
+            r = mul(x, g);
+        } else if constexpr (FLAGS & 8) {
+            r = mul(x, fe_from<Fr>(A.post_const));
+        } else {
+            r = reduce_value(x);
+        }
+        to_canonical(r, w);
+    }
+    store8(A.out + (size_t)blockIdx.y * A.out_bstride + 8 * gidx, w);
+}
+
+template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) ntt_pass_fused_kernel(NttPassArgs A)
+{
+    extern __shared__ uint32_t lds[]; // [9][cols * S]
+    const uint32_t S = 1u << A.log_s, cols = A.cols, E = cols * S, quarter = S >> 2, ngr = cols * quarter;
+    uint32_t bid = blockIdx.x;
+    if (A.xcd_remap && (gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t b0 = bid * cols;
+    const uint32_t tid = threadIdx.x;
+    using In = Fe<Fr, 1, 6>; // what unpack() / the pre-scale product really hold
+
+    // ---- A: load (+ coset pre-scale) + stage pair (0, 1) ------------------------------------------------------------------
+    for (uint32_t gq = tid; gq < ngr; gq += THREADS) {
+        uint32_t c, t;
+        if (A.b_fast) { c = gq & (cols - 1); t = gq >> A.log_cols; } else { t = gq & (quarter - 1); c = gq >> (A.log_s - 2); }
+        In x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const size_t gidx = (size_t)(t + j * quarter) * A.in_sa + (size_t)(b0 + c) * A.in_sb;
+            uint32_t w[8];
+            load8(A.in + (size_t)blockIdx.y * A.in_bstride + 8 * gidx, w);
+            x[j] = unpack<Fr>(w);
+            if constexpr (FLAGS & 1) {
+                const uint32_t i = (uint32_t)gidx; // natural coefficient index
+                auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
+                x[j] = mul(x[j], g);
+            }
+        }
+        // row t + j S/4 sits at bit-reversed index 4 bitrev(t) + bitrev2(j): the group of LDS indices 4q .. 4q + 3 is rows (0, 2, 1, 3)
+        const uint32_t q = bitrev(t, A.log_s - 2), cb = c * S;
+        const In &z0 = x[0], &z1 = x[2], &z2 = x[1], &z3 = x[3];
+        FrL y0, y1, y2, y3;
+        if (A.debug_skip & 1) {
+            y0 = z0; y1 = z1; y2 = z2; y3 = z3;
+        } else {
+            const auto a0 = add(z0, z1);
+            const auto a1 = sub(z0, z1);
+            const auto a2 = add(z2, z3);
+            const auto a3 = sub(z2, z3);
+            const FeT<Fr> w4 = load_tw(A.tw_sub, 1u << (A.log_s - 2)); // w_S^(S/4)
+            const auto u3 = mul(w4, a3);                               // < 3p
+            y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, a2)));
+            y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, a2)));
+            y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
+            y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
+        }
+        const uint32_t e0 = cb + lds_pos(4 * q), e1 = cb + lds_pos(4 * q + 1), e2 = cb + lds_pos(4 * q + 2), e3 = cb + lds_pos(4 * q + 3);
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            lds[l * E + e0] = y0.d[l];
+            lds[l * E + e1] = y1.d[l];
+            lds[l * E + e2] = y2.d[l];
+            lds[l * E + e3] = y3.d[l];
+        }
+    }
+    __syncthreads();
+
+    // ---- B: middle stage pairs in LDS ----------------------------------------------------------------------------------------
+    const bool odd = (A.log_s & 1) != 0;
+    const uint32_t last_s = odd ? A.log_s - 1 : A.log_s - 2; // first stage of the part fused with the store
+    uint32_t s = (A.debug_skip & 1) ? last_s : 2;
+    for (; s < last_s; s += 2) {
+        const uint32_t m = 1u << s;
+        for (uint32_t gq = tid; gq < ngr; gq += THREADS) {
+            const uint32_t c = gq >> (A.log_s - 2), q = gq & (quarter - 1);
+            const uint32_t j = q & (m - 1);
+            const uint32_t i0 = ((q >> s) << (s + 2)) | j, cb = c * S;
+            const uint32_t e0 = cb + lds_pos(i0), e1 = cb + lds_pos(i0 + m), e2 = cb + lds_pos(i0 + 2 * m), e3 = cb + lds_pos(i0 + 3 * m);
+            FrL x0, x1, x2, x3;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                x0.d[l] = lds[l * E + e0];
+                x1.d[l] = lds[l * E + e1];
+                x2.d[l] = lds[l * E + e2];
+                x3.d[l] = lds[l * E + e3];
+            }
+            const FeT<Fr> w1 = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
+            const auto t1 = mul(w1, x1), t3 = mul(w1, x3); // < 3p
+            const auto a0 = add(x0, t1);
+            const auto a1 = sub(x0, t1);
+            const auto a2 = add(x2, t3);
+            const auto a3 = sub(x2, t3);
+            const FeT<Fr> w2a = load_tw(A.tw_sub, j << (A.log_s - 2 - s));
+            const FeT<Fr> w2b = load_tw(A.tw_sub, (j + m) << (A.log_s - 2 - s));
+            const auto u2 = mul(w2a, a2), u3 = mul(w2b, a3); // < 3p
+            const FrL y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, u2)));
+            const FrL y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, u2)));
+            const FrL y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
+            const FrL y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                lds[l * E + e0] = y0.d[l];
+                lds[l * E + e1] = y1.d[l];
+                lds[l * E + e2] = y2.d[l];
+                lds[l * E + e3] = y3.d[l];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- C: last stage pair (even log_s) or last stage (odd) + twist / scaling / canonicalisation + store -----------------------
+    if (!odd) {
+        const uint32_t m = quarter; // s = log_s - 2
+        for (uint32_t gq = tid; gq < ngr; gq += THREADS) {
+            uint32_t c, j;
+            if (A.store_b_fast) { c = gq & (cols - 1); j = gq >> A.log_cols; } else { j = gq & (quarter - 1); c = gq >> (A.log_s - 2); }
+            const uint32_t cb = c * S;
+            FrL x0, x1, x2, x3;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                x0.d[l] = lds[l * E + cb + lds_pos(j)];
+                x1.d[l] = lds[l * E + cb + lds_pos(j + m)];
+                x2.d[l] = lds[l * E + cb + lds_pos(j + 2 * m)];
+                x3.d[l] = lds[l * E + cb + lds_pos(j + 3 * m)];
+            }
+            FrL y0, y1, y2, y3;
+            if (A.debug_skip & 1) {
+                y0 = x0; y1 = x1; y2 = x2; y3 = x3;
+            } else {
+                const FeT<Fr> w1 = load_tw(A.tw_sub, j << 1);
+                const auto t1 = mul(w1, x1), t3 = mul(w1, x3);
+                const auto a0 = add(x0, t1);
+                const auto a1 = sub(x0, t1);
+                const auto a2 = add(x2, t3);
+                const auto a3 = sub(x2, t3);
+                const FeT<Fr> w2a = load_tw(A.tw_sub, j);
+                const FeT<Fr> w2b = load_tw(A.tw_sub, j + m);
+                const auto u2 = mul(w2a, a2), u3 = mul(w2b, a3);
+                y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, u2)));
+                y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, u2)));
+                y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
+                y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
+            }
+            const uint32_t b = b0 + c;
+            ntt_finish_store<FLAGS>(A, y0, j, b);
+            ntt_finish_store<FLAGS>(A, y1, j + m, b);
+            ntt_finish_store<FLAGS>(A, y2, j + 2 * m, b);
+            ntt_finish_store<FLAGS>(A, y3, j + 3 * m, b);
+        }
+    } else {
+        const uint32_t half = S >> 1, nbf = cols * half; // s = log_s - 1
+        for (uint32_t bf = tid; bf < nbf; bf += THREADS) {
+            uint32_t c, j;
+            if (A.store_b_fast) { c = bf & (cols - 1); j = bf >> A.log_cols; } else { j = bf & (half - 1); c = bf >> (A.log_s - 1); }
+            const uint32_t cb = c * S;
+            FrL x, y;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                x.d[l] = lds[l * E + cb + lds_pos(j)];
+                y.d[l] = lds[l * E + cb + lds_pos(j + half)];
+            }
+            FrL xs, ys;
+            if (A.debug_skip & 1) {
+                xs = x; ys = y;
+            } else {
+                const FeT<Fr> w = load_tw(A.tw_sub, j);
+                const auto t = mul(w, y);
+                xs = assume_bound<1, NTT_VMAX>(weak(add(x, t)));
+                ys = assume_bound<1, NTT_VMAX>(weak(sub(x, t)));
+            }
+            const uint32_t b = b0 + c;
+            ntt_finish_store<FLAGS>(A, xs, j, b);
+            ntt_finish_store<FLAGS>(A, ys, j + half, b);
+        }
+    }
+}
+
 // table[k] = base^k * factor   (all Montgomery-261), k < count; canonical, as nine exact 29-bit limbs in a 12-word entry
 __global__ void ntt_pow_table_kernel(uint32_t* table, uint32_t count, Limbs9 base, Limbs9 factor)
 {
@@ -433,6 +643,20 @@ hipError_t get_domain(int log2n, hipStream_t st, DomainTables** out)
     return hipSuccess;
 }
 
+// elements per workgroup tile (the fused kernel): 1024 (36 KiB, four workgroups of 256 threads per CU), 2048 (72 KiB, two of 512) or 4096
+// (144 KiB, one of 1024: the strided side of a pass then moves rows twice as wide).  Measured (tools/ntt_sizes.py, one box, fft):
+//   tile   2^12    2^14    2^16    2^18    2^20    2^22    2^24
+//   1024  0.031   0.033   0.035   0.050   0.133   0.531   2.17  ms   <- below 2^20 transforms are latency-bound: twice the workgroups, half the barrier width
+//   2048  0.055   0.052   0.053   0.064   0.130   0.527   2.16
+//   4096  0.089   0.100   0.092   0.102   0.131   0.543   2.38       <- wider rows buy nothing: the passes are not bound by coalescing
+// BBGPU_NTT_TILE overrides.
+uint32_t ntt_tile_elems(int log2n)
+{
+    static const int forced = [] { const char* e = getenv("BBGPU_NTT_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 1024 || forced == 2048 || forced == 4096) return (uint32_t)forced;
+    return log2n > 0 && log2n < 20 ? NTT_LDS_ELEMS / 2 : NTT_LDS_ELEMS;
+}
+
 template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st)
 {
     const uint32_t S = 1u << A.log_s, blocks = (1u << A.log_b) / A.cols;
@@ -440,9 +664,26 @@ template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
+        (void)hipFuncSetAttribute((const void*)ntt_pass_fused_kernel<FLAGS, NTT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
+        (void)hipFuncSetAttribute((const void*)ntt_pass_fused_kernel<FLAGS, 2 * NTT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NTT_LDS_ELEMS * NL * 4);
+        (void)hipFuncSetAttribute((const void*)ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
         attr_set = true;
     }
-    ntt_pass_kernel<FLAGS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(A);
+    // sub-transforms of 16 points and more take the kernel with load / store fused into the first / last stage pair (BBGPU_NTT_FUSED=0: A/B)
+    static const bool fused_on = [] { const char* e = getenv("BBGPU_NTT_FUSED"); return !e || atoi(e) != 0; }();
+    if (fused_on && A.log_s >= 4) {
+        NttPassArgs B = A;
+        B.store_b_fast = (A.out_sb == 1 && A.cols > 1) ? 1u : 0u;
+        if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) // double tile: one workgroup of 1024 threads per CU (144 KiB of LDS), rows twice as wide
+            ntt_pass_fused_kernel<FLAGS, 2 * NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), 2 * NTT_THREADS, lds, st>>>(B);
+        else if (A.half_tile && (size_t)A.cols * S <= (size_t)NTT_LDS_ELEMS / 2) // half tile: four workgroups of 256 threads per CU
+            ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS / 2, lds, st>>>(B);
+        else
+            ntt_pass_fused_kernel<FLAGS, NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(B);
+    } else {
+        if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) return hipErrorInvalidValue; // the double tile exists in the fused kernel only
+        ntt_pass_kernel<FLAGS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(A);
+    }
     return hipGetLastError();
 }
 
@@ -489,6 +730,7 @@ static int ntt_device_three_pass(uint64_t* d_coeffs, uint64_t* d_scratch, int lo
     const Limbs9 pcl = to_limbs(pc);
     const uint32_t n1 = 1u << l1, m = 1u << lm, m1 = 1u << Dm->log_s1, m2 = 1u << Dm->log_s2;
     NttPassArgs A{};
+    A.half_tile = ntt_tile_elems(log2n) == NTT_LDS_ELEMS / 2 ? 1u : 0u;
     A.xcd_remap = 1;
     for (int i = 0; i < NL; i++) A.post_const[i] = pcl.d[i];
     hipError_t e;
@@ -501,7 +743,7 @@ static int ntt_device_three_pass(uint64_t* d_coeffs, uint64_t* d_scratch, int lo
     A.twist_lo = D->twist_lo[inverse]; A.twist_hi = D->twist_hi[inverse];
     A.scale_lo = D->scale_lo[0]; A.scale_hi = D->scale_hi[0];
     A.log_s = (uint32_t)l1; A.log_b = (uint32_t)lm;
-    A.cols = NTT_LDS_ELEMS >> l1; if (A.cols > m) A.cols = m;
+    A.cols = std::max<uint32_t>(1u, ntt_tile_elems(log2n) >> l1); if (A.cols > m) A.cols = m;
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = m; A.in_sb = 1; A.out_sa = m; A.out_sb = 1; A.b_fast = 1;
     if ((e = dispatch(2 | (pre ? 1 : 0), A, st)) != hipSuccess) return BBGPU_ERR_HIP;
@@ -514,7 +756,7 @@ static int ntt_device_three_pass(uint64_t* d_coeffs, uint64_t* d_scratch, int lo
     A.lo_bits = Dm->lo_bits;
     A.twist_lo = Dm->twist_lo[inverse]; A.twist_hi = Dm->twist_hi[inverse];
     A.log_s = Dm->log_s1; A.log_b = Dm->log_s2;
-    A.cols = NTT_LDS_ELEMS >> Dm->log_s1; if (A.cols > m2) A.cols = m2;
+    A.cols = std::max<uint32_t>(1u, ntt_tile_elems(log2n) >> Dm->log_s1); if (A.cols > m2) A.cols = m2;
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = m2; A.in_sb = 1; A.out_sa = m2; A.out_sb = 1; A.b_fast = 1;
     if ((e = dispatch(2, A, st)) != hipSuccess) return BBGPU_ERR_HIP;
@@ -528,7 +770,7 @@ static int ntt_device_three_pass(uint64_t* d_coeffs, uint64_t* d_scratch, int lo
     A.lo_bits = D->lo_bits; // the post-scale tables are those of the size-n domain
     A.scale_lo = D->scale_lo[post_table ? 1 : 0]; A.scale_hi = D->scale_hi[post_table ? 1 : 0];
     A.log_s = Dm->log_s2; A.log_b = Dm->log_s1;
-    A.cols = NTT_LDS_ELEMS >> Dm->log_s2; if (A.cols > m1) A.cols = m1;
+    A.cols = std::max<uint32_t>(1u, ntt_tile_elems(log2n) >> Dm->log_s2); if (A.cols > m1) A.cols = m1;
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = 1; A.in_sb = m2; A.out_sa = m1 * n1; A.out_sb = n1; A.b_fast = 0;
     const int last_flags = 16 | (post_table ? 4 : 0) | (post_const ? 8 : 0);
@@ -583,6 +825,7 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
 
     const uint32_t n1 = 1u << D->log_s1, n2 = 1u << D->log_s2;
     NttPassArgs A{};
+    A.half_tile = ntt_tile_elems(log2n) == NTT_LDS_ELEMS / 2 ? 1u : 0u;
     A.batch = (uint32_t)batch;
     {
         // measured (tools/ntt_sizes.py, fft): 2^22 0.617 -> 0.584 ms, 2^21 0.320 -> 0.302, 2^20 0.153 -> 0.149, 2^18 0.0695 -> 0.0707 (slightly worse)
@@ -616,7 +859,7 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
     A.out_bstride = ((size_t)1 << log2n) * 8;
     A.tw_sub = D->tw_sub[inverse][0];
     A.log_s = D->log_s1; A.log_b = D->log_s2;
-    A.cols = NTT_LDS_ELEMS >> D->log_s1; if (A.cols > n2) A.cols = n2;
+    A.cols = std::max<uint32_t>(1u, ntt_tile_elems(log2n) >> D->log_s1); if (A.cols > n2) A.cols = n2;
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = n2; A.in_sb = 1; A.out_sa = n2; A.out_sb = 1; A.b_fast = 1;
     if ((e = dispatch(2 | (pre ? 1 : 0), A, st)) != hipSuccess) return BBGPU_ERR_HIP;
@@ -627,7 +870,7 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
     A.out_bstride = stride_elems * 8;
     A.tw_sub = D->tw_sub[inverse][1];
     A.log_s = D->log_s2; A.log_b = D->log_s1;
-    A.cols = NTT_LDS_ELEMS >> D->log_s2; if (A.cols > n1) A.cols = n1;
+    A.cols = std::max<uint32_t>(1u, ntt_tile_elems(log2n) >> D->log_s2); if (A.cols > n1) A.cols = n1;
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = 1; A.in_sb = n2; A.out_sa = n1; A.out_sb = 1; A.b_fast = 0;
     if ((e = dispatch(last_flags, A, st)) != hipSuccess) return BBGPU_ERR_HIP;

@@ -261,10 +261,13 @@ def main():
     single = (rank == 0 and world == 1)
     cpu_leg = single and not args.no_cpu_baseline  # the CPU reference is timed at N = 1 only
     host_legs = single and not args.no_boundary   # boundary-inclusive legs need the host copy of the point table
+    if world > 1 and not args.no_window_tables:
+        G.set_table_share(rank, world)  # this rank's 1/N of the (window, point) rows touches ceil(W / N) + 1 digit windows: only those are built and kept
     if cpu_leg or host_legs:
         srs, table = G.srs_generate(x_secret, n, want_host_table=True)
     else:
         srs, table = G.srs_generate(x_secret, n), None
+    G.set_table_share(0, 1)
     d_scalars = to_montgomery_on_device(G, raw_scalars(n, SPLITMIX_GAMMA), dev)
     scalars = d_scalars.cpu().numpy().view(np.uint64) if (cpu_leg or host_legs) else None
     W = G.srs_num_windows(srs, n)
@@ -343,7 +346,9 @@ def main():
     # window-sharded result == the same MSM done by one rank alone (outside the timed region)
     sharded_ok = None
     if world > 1:
-        full = G.msm_device(srs, d_scalars.data_ptr(), n, 0, 0, W)
+        srs_full = G.srs_generate(x_secret, n)  # complete tables, for this check only
+        full = G.msm_device(srs_full, d_scalars.data_ptr(), n, 0, 0, W)
+        G.srs_release(srs_full)
         sharded_ok = bool(np.array_equal(full, res))
 
     # ---- the same stages with nothing else on the GPU (one MSM at a time), for comparison ---------------------------
@@ -351,7 +356,10 @@ def main():
     stage = np.zeros(7)
     reps = 5
     for _ in range(reps):
-        if we > wb:
+        if by_rows:
+            G.msm_wait(G.msm_device_rows_async(srs, d_scalars.data_ptr(), n, rows[0], rows[1]))
+            stage += np.array(G.last_timing()[:7])
+        elif we > wb:
             G.msm_device(srs, d_scalars.data_ptr(), n, 0, wb, we)
             stage += np.array(G.last_timing()[:7])
     stage /= reps

@@ -86,6 +86,11 @@ int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
  * all digit windows share one bucket set.  On by default for 1024 <= n <= 2^20; bbgpu_set_precompute(0) turns it off for
  * tables registered afterwards.  Results are identical either way. */
 void bbgpu_set_precompute(int enabled);
+/* Multi-GPU: tables registered after this call keep only the digit windows that rank `rank` of `world` touches when the W x n (window,
+ * point) rows are split evenly over the ranks (bbgpu_msm_g1_device_rows_async with rows [W n r / N, W n (r + 1) / N), or whole-window
+ * shares inside that range): ceil(W / world) + 1 windows instead of W.  Asking such a table for other windows returns BBGPU_ERR_STATE.
+ * (0, 1) restores full tables. */
+void bbgpu_set_table_share(int rank, int world);
 /* number of digit windows an MSM of n points against this table is split into (use this, not bbgpu_msm_num_windows, to
  * shard windows over ranks: a table carries the window size it was built for) */
 int bbgpu_srs_num_windows(int srs_handle, size_t n);
@@ -107,7 +112,12 @@ int bbgpu_transcript_write(const char* path, const uint64_t* points_endo_table, 
 int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out);
 
 /* drop-in for scalar_multiplication::pippenger(scalars, points, n, bucket_width) (:457-476); scalars not modified.
- * out = {x, y, z} normalised, or infinity flag set (n == 0, all-zero scalars). */
+ * out = {x, y, z} normalised, or infinity flag set (n == 0, all-zero scalars).
+ * Representation note: a sum that IS the point at infinity comes back as the clean encoding (all limbs zero, bit 63 of y limb 3 set).
+ * The reference's Prover pushes such a result through g1::jacobian_to_affine (prover.cpp:73-132), which leaves whatever the CPU
+ * algorithm's accumulators held in x, y -- an unspecified off-curve pair that only the reference's own code path reproduces; a proof
+ * that commits to an all-zero polynomial (zero selector, all-zero witness) therefore hashes differently under the two builds.  Every
+ * other result is the unique affine point and is bit-identical. */
 int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12]);
 /* SURVEY 8b "small sizes": the reference's callers include the Verifier's per-proof MSM over ~20 freshly built points
  * (verifier.cpp:359-363) and proofs of n = 4 circuits (test_verifier.cpp:105-122).  Host-pointer MSMs of at most `msm_max_points`

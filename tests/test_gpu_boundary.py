@@ -132,6 +132,31 @@ def test_null_stream_is_the_default_stream(gpu, oracle):
         assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
 
 
+def test_rank_share_of_the_window_tables(gpu, oracle, tables):
+    """multi-GPU memory layout: a rank keeps only the digit windows its 1/N share of the (window, point) rows touches (bbgpu_set_table_share);
+    the eight shares, each against its own restricted table, still fold to the MSM, and windows outside the share are refused"""
+    import torch
+    from barretenberg_amd import BbGpuError
+    (A, B, C), small, sc = tables
+    n = 2048
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    want = oracle.msm_affine(sc, A, n)
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            gpu.set_table_share(r, world)
+            h = gpu.srs_register(aligned_copy(A))
+            gpu.set_table_share(0, 1)
+            W = gpu.srs_num_windows(h, n)
+            R = W * n
+            parts.append(gpu.msm_wait(gpu.msm_device_rows_async(h, d.data_ptr(), n, R * r // world, R * (r + 1) // world)))
+            if r == 0 and world == 8:
+                with pytest.raises(BbGpuError, match="keeps"):
+                    gpu.msm_device(h, d.data_ptr(), n)  # the full window range is not resident on this rank
+            gpu.srs_release(h)
+        assert np.array_equal(gpu.g1_sum(np.stack(parts))[:8], want[:8]), world
+
+
 def test_partial_sum_exchange_over_rccl_world_size_1(gpu, oracle, tables):
     """the multi-GPU MSM's one exchange step over backend nccl (= RCCL) with the ranks this box has: init, all_gather of the
     96-byte partial sums on the GPU, identical fold -- the same objects bench.py uses for N > 1 (barretenberg_amd/sharding.py)"""

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Regenerates every file under profiles/ that the roofline numbers come from, from the CURRENT binary, in one gpurun call:
+#   tools/collect_profiles.sh <tag>        (tag = r02 ...; outputs land in gpurun_out/prof_<tag>/, summaries are copied by hand)
+# Counter passes carry --pmc only (no tracing domains), one counter group per pass, as MI355X_MICROARCH.md prescribes.
+set -o pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-plonk --no-boundary"
+BENCH_PMC="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary"
+echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
+echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH_PMC > $OUT/fetch.log 2>&1 || exit 1
+echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH_PMC > $OUT/write.log 2>&1 || exit 1
+echo "== calibration FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- $ROOT/tools/ubench/ubench_traffic > $OUT/cal_fetch.log 2>&1 || exit 1
+echo "== calibration WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $ROOT/tools/ubench/ubench_traffic > $OUT/cal_write.log 2>&1 || exit 1
+echo "== SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary > $OUT/sq.log 2>&1 || exit 1
+echo "== prover trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/plonk -- python3 $ROOT/tools/plonk_bench.py --reps 10 --no-reference > $OUT/plonk.log 2>&1 || exit 1
+cd $ROOT
+echo "== summaries"
+python tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/${TAG}_pmc_traffic.json
+python tools/pmc_sq_summary.py $OUT/sq $OUT/${TAG}_pmc_sq.json
+python tools/acc_spacing.py $OUT/trace | tee $OUT/acc_spacing.txt
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bench_steps10.csv
+cp $(find $OUT/plonk -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_plonk_prover_2e16.csv
+$ROOT/tools/ubench/ubench_traffic > $OUT/ubench_traffic.txt 2>&1
+# keep the merged scratch small: the raw traces of the counter passes are not needed once summarised
+rm -rf $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/sq
+find $OUT/trace $OUT/plonk -name "*kernel_trace.csv" -size +20M -delete
+echo "== plain bench line"
+python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
+tail -c 400 $OUT/${TAG}_bench_line.json

@@ -67,7 +67,7 @@ def main():
         kernels[k] = {"launches": len(fetch.get(k, [])), "fetch_bytes_raw": f, "write_bytes_raw": w, "calibration_shape": sh,
                       "fetch_bytes": f * ff, "write_bytes": w * wf, "total_bytes": f * ff + w * wf}
     acc = kernels.get("bbgpu::msm_accumulate_kernel", {})
-    ntt = [v for k, v in kernels.items() if "ntt_pass_kernel" in k]
+    ntt = [v for k, v in kernels.items() if "ntt_pass" in k]
     # bench.py --no-boundary launches 2^20-point transforms only: one transform = one pass-1 launch + one pass-2 launch
     ntt_total = sum(v["total_bytes"] * v["launches"] for v in ntt) / max(1, sum(v["launches"] for v in ntt)) * 2 if ntt else None
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing domains) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary; "
