@@ -533,8 +533,10 @@ constexpr int RAW_WORDS = 4 * NL; // 36 words per partial: lazy limbs, no canoni
 
 __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ gstart, uint32_t* __restrict__ partials,
-                                                                   uint32_t total_buckets, uint32_t ch, uint32_t prio)
+                                                                   uint32_t total_buckets, uint32_t ch, uint32_t prio, uint32_t* __restrict__ heavy_counter)
 {
+    // small MSMs are a chain of dependent launches: the merge's heavy-bucket counter is zeroed here instead of by a fill launch of its own
+    if (heavy_counter && blockIdx.x == 0 && threadIdx.x == 0) *heavy_counter = 0;
     // wave priority above the memory-bound sort kernels of the NEXT MSM that share the CUs in the two-deep pipeline (they have
     // a whole accumulation of slack), below the latency-bound tail kernels of the previous one (s_setprio 3)
     if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -717,11 +719,15 @@ __device__ __forceinline__ uint32_t insert_one_bit(uint32_t m, uint32_t k)
 // Row sums R[hi] = sum_lo B[hi][lo] (blockIdx.x < H) and column sums C[lo] = sum_hi B[hi][lo] (blockIdx.x >= H) of the
 // H x L bucket matrix of group blockIdx.y; blockDim.x = max(H, L).
 __global__ void __launch_bounds__(FOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
-                                                          uint32_t H, uint32_t L)
+                                                          uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[FOLD_LDS_WORDS];
     const uint32_t g = blockIdx.y, t = threadIdx.x, nb = H * L;
+    if (zero_out) { // small MSMs: the export slots (infinity = all zero) are cleared here instead of by a fill launch
+        const uint32_t gid = (g * gridDim.x + blockIdx.x) * blockDim.x + t, all = gridDim.y * gridDim.x * blockDim.x;
+        for (uint32_t i = gid; i < zero_words; i += all) zero_out[i] = 0;
+    }
     const bool row = blockIdx.x < H;
     const uint32_t idx = row ? blockIdx.x : blockIdx.x - H, count = row ? L : H;
     Xyzz acc;
@@ -1085,17 +1091,24 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     // -- but no wider than what fills the chip once (~2^16 lanes): beyond that the extra lanes only add issue work
     const uint32_t avg_partials = (uint32_t)(((uint64_t)n * nw) / ((uint64_t)G * P.nb * ch)) + 1;
     uint32_t logG = 0;
-    while ((1u << logG) < avg_partials && logG < 6 && ((uint64_t)G * P.nb << (logG + 1)) <= (1u << 16)) logG++;
+    static const uint32_t lanes_log = [] { const char* e = getenv("BBGPU_MERGE_LANES_LOG"); return e ? (uint32_t)std::min(20, std::max(14, atoi(e))) : 16u; }(); // tuning knob
+    while ((1u << logG) < avg_partials && logG < 6 && ((uint64_t)G * P.nb << (logG + 1)) <= ((uint64_t)1 << lanes_log)) logG++;
     const uint32_t merge_light = std::max(6u, 8u << logG);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
-    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch, acc_prio());
+    // Small MSMs (the prover's 2^16-point commitments, a rank's share of an 8-way split) are chains of dependent launches: their three
+    // helper launches -- two fills and the device-to-host copy -- are folded into the kernels around them, the last kernel writing the 8 KiB
+    // of results straight into the pinned host buffer.  Not for the full-size pipelined step: there the earlier tail collides with the
+    // next accumulation's start (measured in round 1: +1..3 % per step).
+    static const int fold_env = [] { const char* e = getenv("BBGPU_FOLD_TAIL"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force
+    const bool fold = fold_env >= 0 ? fold_env != 0 : ((uint64_t)n * nw <= ((uint64_t)1 << 22));
+    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch, acc_prio(), fold ? heavy : nullptr);
     if (tm_acc) {
         HIPCHK(hipEventRecord(ev[3], st));
         if (int rc = acc_ring_record(S, st)) return rc;
     } else {
         S.acc_seq = 0;
     }
-    HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
+    if (!fold) HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
     msm_merge_kernel<<<(uint32_t)((((uint64_t)total_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
                                                                                                                      total_buckets, ch, merge_light, logG);
     msm_merge_heavy_kernel<<<256, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
@@ -1109,13 +1122,15 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         // row + column sums in one launch (one workgroup tree per row / column), then Z and the bit-sliced sums in a second
         uint32_t* Rr = scratch;
         uint32_t* Cc = scratch + (size_t)G * H * 32;
-        msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L);
+        uint32_t* dest = fold ? (uint32_t*)ws.h_out : texp; // pinned host memory is device-accessible under the same pointer
+        const uint32_t zero_words = G * 64 * 32;
+        msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
         if (tm) HIPCHK(hipEventRecord(ev[5], st));
-        HIPCHK(hipMemsetAsync(texp, 0, (size_t)G * 64 * 128, st)); // unused slots = infinity (zz = 0)
-        msm_final_kernel<<<dim3(1 + P.hbits + P.lbits, G), std::max(H, L), 0, st>>>(Rr, Cc, texp, P.hbits, P.lbits);
+        if (!fold) HIPCHK(hipMemsetAsync(texp, 0, (size_t)G * 64 * 128, st)); // unused slots = infinity (zz = 0)
+        msm_final_kernel<<<dim3(1 + P.hbits + P.lbits, G), std::max(H, L), 0, st>>>(Rr, Cc, dest, P.hbits, P.lbits);
         if (tm) HIPCHK(hipEventRecord(ev[6], st));
     }
-    HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
+    if (!fold) HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(S.done, st));
     HIPCHK(hipGetLastError());
     S.pending = true;
