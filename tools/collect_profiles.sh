@@ -28,6 +28,11 @@ $ROOT/tools/ubench/ubench_traffic > $OUT/ubench_traffic.txt 2>&1
 # keep the merged scratch small: the raw traces of the counter passes are not needed once summarised
 rm -rf $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/sq
 find $OUT/trace $OUT/plonk -name "*kernel_trace.csv" -size +20M -delete
+echo "== shard prediction"
+python tools/shard_sim.py $OUT/${TAG}_shard_prediction.json > $OUT/shard_sim.txt 2>&1; tail -6 $OUT/shard_sim.txt
+python tools/ntt_sizes.py > $OUT/ntt_sizes.txt 2>&1
+python tools/msm_ab.py > $OUT/msm_ab.txt 2>&1
+python tools/small_sizes.py > $OUT/small_sizes.txt 2>&1
 echo "== plain bench line"
 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 tail -c 400 $OUT/${TAG}_bench_line.json
