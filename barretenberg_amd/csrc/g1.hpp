@@ -116,6 +116,43 @@ template <int V> BB_HD void madd(Xyzz& acc, const AffineV<V>& a)
     acc.zzz = ZZZ3;
 }
 
+// The same for the bucket accumulation's hot loop, where the two rare tests are the only non-arithmetic work per addition: the
+// accumulator's infinity is carried as a flag (set at a bucket start and by P + (-P)) instead of nine ORs over zz, and the full
+// "PP == 0 (mod p)" comparison (27 compares over the limbs) runs only when limb 0 of PP is one of the three values it can have then.
+template <int V> BB_HD void madd_flagged(Xyzz& acc, bool& acc_inf, const AffineV<V>& a)
+{
+    if (acc_inf) {
+        from_affine(acc, a);
+        acc_inf = false;
+        return;
+    }
+    auto U2 = mul(a.x, acc.zz);
+    auto S2 = mul(a.y, acc.zzz);
+    auto P = weak(sub(U2, acc.x));
+    auto R = weak(sub(S2, acc.y));
+    auto PP = sqr(P);
+    constexpr Limbs9 p2 = make_multiple<Fq>(2);
+    if ((PP.d[0] == 0 || PP.d[0] == Fq::P[0] || PP.d[0] == p2.d[0]) && is_zero_mulout(PP)) { // same x: rare
+        if (is_zero_slow(R)) {
+            dbl_affine(acc, a);
+        } else {
+            set_infinity(acc);
+            acc_inf = true;
+        }
+        return;
+    }
+    auto PPP = mul(P, PP);
+    auto Q = mul(acc.x, PP);
+    auto X3 = weak(sub(sqr(R), add(PPP, dbl(Q))));
+    auto Y3 = mul_sub(R, sub(Q, X3), acc.y, PPP);
+    auto ZZ3 = mul(acc.zz, PP);
+    auto ZZZ3 = mul(acc.zzz, PPP);
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = ZZ3;
+    acc.zzz = ZZZ3;
+}
+
 // r = p + q   [add-2008-s], 12M + 2S, all exceptional cases
 BB_HD void add(Xyzz& r, const Xyzz& p, const Xyzz& q)
 {

@@ -556,8 +556,9 @@ __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kerne
     uint32_t next_end = gstart[b + 1];
     Xyzz acc;
     set_infinity(acc);
+    bool acc_inf = true; // the accumulator's infinity as a flag (madd_flagged)
     // software pipeline: the gather of entry e+1 (index, then 64 bytes of point, possibly from HBM when the window
-    // tables exceed the Infinity Cache) is in flight while the ~2,300 VALU instructions of the mixed addition of entry e run
+    // tables exceed the Infinity Cache) is in flight while the ~2,200 VALU instructions of the mixed addition of entry e run
     // The INDEX runs two entries ahead: the gather address of entry e+1 is then known when iteration e starts, instead of costing an
     // index-load latency before the gather can even be issued.
     uint32_t v = sorted[p0];
@@ -571,11 +572,12 @@ __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kerne
         if (e == next_end) {
             store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
             set_infinity(acc);
+            acc_inf = true;
             do { b++; next_end = gstart[b + 1]; } while (next_end <= e); // skip empty buckets
         }
         AffineV<1> p;
         load_affine_m261(p, w);
-        madd(acc, cond_neg_affine(p, (v >> 31) != 0));
+        madd_flagged(acc, acc_inf, cond_neg_affine(p, (v >> 31) != 0));
         v = vn;
         vn = vnn;
 #pragma unroll
