@@ -37,6 +37,7 @@ constexpr int NTT_MAX_LOG2N = 28;            // two-adicity of r - 1 (fr.hpp:60-
 constexpr int NTT_MAX_LOG_SUB = 11;          // sub-transform up to 2048 points (72 KiB of LDS)
 constexpr int NTT_LDS_ELEMS = 2048;          // elements of LDS per workgroup (9 words each = 72 KiB) -> 2 WG / CU
 constexpr int NTT_THREADS = 512;
+constexpr int NTT_FULL_TWIST_MAX_LOG2N = 22; // 2 x n x 32 B of twist factors per domain: 256 MiB at 2^22
 
 // proof obligation is the caller's: the true bounds are <= (L, V)
 template <int L, int V, class F, int L2, int V2> BB_HD Fe<F, L, V> assume_bound(const Fe<F, L2, V2>& a)
@@ -94,6 +95,7 @@ struct NttPassArgs {
     const uint32_t* tw_sub;   // w_S^k, k < S/2
     const uint32_t* twist_lo; // w_n^l, l < 2^lo_bits          (pass 1 only)
     const uint32_t* twist_hi; // w_n^(h << lo_bits)
+    const uint32_t* twist_full; // FLAGS & 32: w_n^(b k) for every element of pass 1's output, packed 8 words, in the output's own layout
     const uint32_t* scale_lo; // g^l (pre) or g^-l (post) two-level tables, lo part
     const uint32_t* scale_hi;
     uint32_t post_const[NL];  // Montgomery-261 constant applied to every output of the last pass
@@ -296,6 +298,13 @@ template <int FLAGS> __device__ __forceinline__ void ntt_finish_store(const NttP
     uint32_t w[8];
     if ((A.debug_skip & 2) != 0) {
         pack(assume_bound<1, 2>(x), w);
+    } else if constexpr ((FLAGS & 2) && (FLAGS & 32)) {
+        // one multiplication per element: the twist factor comes from a table as large as the vector, read exactly like the output is written
+        uint32_t tw8[8];
+        load8(A.twist_full + 8 * gidx, tw8);
+        const FeT<Fr> tw = assume_bound<1, 1>(unpack<Fr>(tw8));
+        auto r = mul(x, tw);
+        pack(r, w);
     } else if constexpr (FLAGS & 2) {
         const uint32_t ex = b * k; // < n
         auto tw = mul(load_tw(A.twist_lo, ex & ((1u << A.lo_bits) - 1)), load_tw(A.twist_hi, ex >> A.lo_bits));
@@ -507,6 +516,18 @@ __global__ void ntt_pow_table_kernel(uint32_t* table, uint32_t count, Limbs9 bas
     q[2] = make_uint4(u.d[8], 0u, 0u, 0u);
 }
 
+// full[k * n2 + b] = w_n^(b k), k < n1, b < n2, from the two-level tables; canonical, packed 8 words (the layout of pass 1's output)
+__global__ void ntt_twist_full_kernel(uint32_t* full, const uint32_t* lo, const uint32_t* hi, uint32_t lo_bits, uint32_t log_n2, uint32_t n)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t b = g & ((1u << log_n2) - 1), k = g >> log_n2, ex = b * k;
+    auto tw = mul(load_tw(lo, ex & ((1u << lo_bits) - 1)), load_tw(hi, ex >> lo_bits));
+    uint32_t w[8];
+    to_canonical(tw, w);
+    store8(full + 8 * (size_t)g, w);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -539,6 +560,7 @@ struct DomainTables {
     uint32_t* tw_sub3[2] = { nullptr, nullptr };                             // [inverse]: pass A of a three-pass transform (n > 2^22)
     uint32_t* twist_lo[2] = { nullptr, nullptr };                            // [inverse]
     uint32_t* twist_hi[2] = { nullptr, nullptr };
+    uint32_t* twist_full[2] = { nullptr, nullptr };                          // [inverse]: one factor per element (two-pass sizes up to NTT_FULL_TWIST_MAX_LOG2N)
     uint32_t* scale_lo[2] = { nullptr, nullptr };                            // [0]: g^i, [1]: g^-i * n^-1
     uint32_t* scale_hi[2] = { nullptr, nullptr };
     Limbs9 n_inv;                                                            // Montgomery-261
@@ -553,6 +575,13 @@ hipError_t pow_table(uint32_t** out, uint32_t count, const H& base, const H& fac
     if (e != hipSuccess) return e;
     ntt_pow_table_kernel<<<(count + 127) / 128, 128, 0, st>>>(*out, count, to_limbs(base), to_limbs(factor));
     return hipGetLastError();
+}
+
+// one multiplication per element for the inter-pass twist (a table as large as the vector) instead of two (two sqrt(n)-sized tables); BBGPU_NTT_FULL_TWIST=0: A/B
+bool full_twist_enabled()
+{
+    static const bool on = [] { const char* e = getenv("BBGPU_NTT_FULL_TWIST"); return !e || atoi(e) != 0; }();
+    return on;
 }
 
 hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
@@ -596,6 +625,12 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
         }
         if ((e = pow_table(&D->twist_lo[inv], 1u << D->lo_bits, w, one, st)) != hipSuccess) return e;
         if ((e = pow_table(&D->twist_hi[inv], 1u << (log2n - D->lo_bits), h_pow2k(w, D->lo_bits), one, st)) != hipSuccess) return e;
+        if (full_twist_enabled() && !three && D->log_s2 > 0 && log2n <= NTT_FULL_TWIST_MAX_LOG2N) {
+            const uint32_t n = 1u << log2n;
+            if ((e = hipMalloc((void**)&D->twist_full[inv], (size_t)n * 32)) != hipSuccess) return e;
+            ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->twist_full[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
     }
     // coset scale tables: [0] g^i ; [1] g^-i * n^-1   (generator 5: fr.hpp:66-74)
     H g = h_from(Fr::GEN5), gi = h_from(Fr::GEN5_INV);
@@ -615,6 +650,7 @@ void free_domain(DomainTables* D)
         if (D->tw_sub3[i]) (void)hipFree(D->tw_sub3[i]);
         if (D->twist_lo[i]) (void)hipFree(D->twist_lo[i]);
         if (D->twist_hi[i]) (void)hipFree(D->twist_hi[i]);
+        if (D->twist_full[i]) (void)hipFree(D->twist_full[i]);
         if (D->scale_lo[i]) (void)hipFree(D->scale_lo[i]);
         if (D->scale_hi[i]) (void)hipFree(D->scale_hi[i]);
     }
@@ -691,7 +727,7 @@ hipError_t dispatch(int flags, const NttPassArgs& A, hipStream_t st)
 {
     switch (flags) {
 #define CASE(F) case F: return launch_pass<F>(A, st);
-        CASE(2) CASE(3)                                   // pass 1: twist, optionally pre-scaled
+        CASE(2) CASE(3) CASE(34) CASE(35)                 // pass 1: twist (two-level tables / full table), optionally pre-scaled
         CASE(16) CASE(17) CASE(20) CASE(24) CASE(25) CASE(28) // last pass variants
 #undef CASE
     default: return hipErrorInvalidValue;
@@ -862,7 +898,8 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
     A.cols = std::max<uint32_t>(1u, ntt_tile_elems(log2n) >> D->log_s1); if (A.cols > n2) A.cols = n2;
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = n2; A.in_sb = 1; A.out_sa = n2; A.out_sb = 1; A.b_fast = 1;
-    if ((e = dispatch(2 | (pre ? 1 : 0), A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    A.twist_full = D->twist_full[inverse];
+    if ((e = dispatch(2 | (pre ? 1 : 0) | (A.twist_full ? 32 : 0), A, st)) != hipSuccess) return BBGPU_ERR_HIP;
     // pass 2: rows (a = j2, b = k1), scratch -> coeffs transposed: X[k1 + n1 * k2]
     A.in = (const uint32_t*)d_scratch;
     A.out = (uint32_t*)d_coeffs;
