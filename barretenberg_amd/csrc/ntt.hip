@@ -95,6 +95,7 @@ struct NttPassArgs {
     const uint32_t* tw_sub;   // w_S^k, k < S/2
     const uint32_t* twist_lo; // w_n^l, l < 2^lo_bits          (pass 1 only)
     const uint32_t* twist_hi; // w_n^(h << lo_bits)
+    const uint32_t* row_scale;  // FLAGS & 64: factor per INPUT row a of the sub-transform (coset pre-scale), FLAGS & 128: per OUTPUT index k (coset post-scale); 12-word entries
     const uint32_t* twist_full; // FLAGS & 32: w_n^(b k) for every element of pass 1's output, packed 8 words, in the output's own layout
     const uint32_t* scale_lo; // g^l (pre) or g^-l (post) two-level tables, lo part
     const uint32_t* scale_hi;
@@ -117,6 +118,10 @@ struct NttPassArgs {
 
 // FLAGS: 1 = pre-scale input by scale tables (coset_fft), 2 = twist output (pass 1 of 2),
 //        4 = post-scale by scale tables (coset_ifft), 8 = post-scale by constant, 16 = emit canonical output
+//        fused kernel only: 32 = the twist comes from a full-size table (one multiplication), 64 = pre-scale by a per-row table,
+//        128 = post-scale by a per-output-index table.  64 / 128 are how the coset variants cost ONE extra multiplication per element
+//        instead of two: g^(j1 n2 + j2) = (g^n2)^j1 * g^j2 -- the first factor is a row table of the pass-1 sub-transform, the second is
+//        constant along a column and is folded into the (coset) twist table; likewise g^-(k1 + n1 k2) n^-1 on the way out.
 template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs A)
 {
     extern __shared__ uint32_t lds[]; // [9][cols * S]
@@ -312,7 +317,9 @@ template <int FLAGS> __device__ __forceinline__ void ntt_finish_store(const NttP
         pack(r, w);
     } else {
         Fe<Fr, 1, 3> r;
-        if constexpr ((FLAGS & 4) && (FLAGS & 8)) {
+        if constexpr (FLAGS & 128) {
+            r = mul(x, load_tw(A.row_scale, k));
+        } else if constexpr ((FLAGS & 4) && (FLAGS & 8)) {
             const uint32_t i = (uint32_t)gidx + blockIdx.y * A.nat_bstep;
             auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
             r = mul(mul(x, g), fe_from<Fr>(A.post_const));
@@ -351,7 +358,9 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) ntt
             uint32_t w[8];
             load8(A.in + (size_t)blockIdx.y * A.in_bstride + 8 * gidx, w);
             x[j] = unpack<Fr>(w);
-            if constexpr (FLAGS & 1) {
+            if constexpr (FLAGS & 64) {
+                x[j] = mul(x[j], load_tw(A.row_scale, t + j * quarter));
+            } else if constexpr (FLAGS & 1) {
                 const uint32_t i = (uint32_t)gidx; // natural coefficient index
                 auto g = mul(load_tw(A.scale_lo, i & ((1u << A.lo_bits) - 1)), load_tw(A.scale_hi, i >> A.lo_bits));
                 x[j] = mul(x[j], g);
@@ -516,13 +525,17 @@ __global__ void ntt_pow_table_kernel(uint32_t* table, uint32_t count, Limbs9 bas
     q[2] = make_uint4(u.d[8], 0u, 0u, 0u);
 }
 
-// full[k * n2 + b] = w_n^(b k), k < n1, b < n2, from the two-level tables; canonical, packed 8 words (the layout of pass 1's output)
-__global__ void ntt_twist_full_kernel(uint32_t* full, const uint32_t* lo, const uint32_t* hi, uint32_t lo_bits, uint32_t log_n2, uint32_t n)
+// full[k * n2 + b] = w_n^(b k) [* extra[b] or extra[k]], k < n1, b < n2, from the two-level tables; canonical, packed 8 words (the
+// layout of pass 1's output).  extra (12-word entries, or null): the column-constant part of a coset scaling (by_k = 0: g^b on the
+// way in; by_k = 1: g^-k n^-1 on the way out).
+__global__ void ntt_twist_full_kernel(uint32_t* full, const uint32_t* lo, const uint32_t* hi, uint32_t lo_bits, uint32_t log_n2, uint32_t n, const uint32_t* extra,
+                                      uint32_t by_k)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     const uint32_t b = g & ((1u << log_n2) - 1), k = g >> log_n2, ex = b * k;
-    auto tw = mul(load_tw(lo, ex & ((1u << lo_bits) - 1)), load_tw(hi, ex >> lo_bits));
+    Fe<Fr, 1, 2> tw = mul(load_tw(lo, ex & ((1u << lo_bits) - 1)), load_tw(hi, ex >> lo_bits));
+    if (extra) tw = mul(tw, load_tw(extra, by_k ? k : b));
     uint32_t w[8];
     to_canonical(tw, w);
     store8(full + 8 * (size_t)g, w);
@@ -561,6 +574,8 @@ struct DomainTables {
     uint32_t* twist_lo[2] = { nullptr, nullptr };                            // [inverse]
     uint32_t* twist_hi[2] = { nullptr, nullptr };
     uint32_t* twist_full[2] = { nullptr, nullptr };                          // [inverse]: one factor per element (two-pass sizes up to NTT_FULL_TWIST_MAX_LOG2N)
+    uint32_t* coset_row[2] = { nullptr, nullptr };        // [0]: (g^n2)^j1, j1 < n1 (pre-scale rows of pass 1); [1]: (g^-n1)^k2, k2 < n2 (post-scale of pass 2; single pass: g^-k n^-1)
+    uint32_t* coset_twist[2] = { nullptr, nullptr };      // [0]: w^(j2 k1) g^j2 (coset_fft); [1]: w^-(j2 k1) g^-k1 n^-1 (coset_ifft); two-pass sizes with a full twist table
     uint32_t* scale_lo[2] = { nullptr, nullptr };                            // [0]: g^i, [1]: g^-i * n^-1
     uint32_t* scale_hi[2] = { nullptr, nullptr };
     Limbs9 n_inv;                                                            // Montgomery-261
@@ -628,7 +643,7 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
         if (full_twist_enabled() && !three && D->log_s2 > 0 && log2n <= NTT_FULL_TWIST_MAX_LOG2N) {
             const uint32_t n = 1u << log2n;
             if ((e = hipMalloc((void**)&D->twist_full[inv], (size_t)n * 32)) != hipSuccess) return e;
-            ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->twist_full[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n);
+            ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->twist_full[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n, nullptr, 0u);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
     }
@@ -638,6 +653,30 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
     if ((e = pow_table(&D->scale_hi[0], 1u << (log2n - D->lo_bits), h_pow2k(g, D->lo_bits), one, st)) != hipSuccess) return e;
     if ((e = pow_table(&D->scale_lo[1], 1u << D->lo_bits, gi, one, st)) != hipSuccess) return e;
     if ((e = pow_table(&D->scale_hi[1], 1u << (log2n - D->lo_bits), h_pow2k(gi, D->lo_bits), ninv, st)) != hipSuccess) return e;
+    // coset scalings at one multiplication per element (fused kernel, FLAGS 64 / 128)
+    if (!three && D->log_s1 >= 4) {
+        if (D->log_s2 == 0) { // single pass: plain row tables over the whole index
+            if ((e = pow_table(&D->coset_row[0], 1u << log2n, g, one, st)) != hipSuccess) return e;
+            if ((e = pow_table(&D->coset_row[1], 1u << log2n, gi, ninv, st)) != hipSuccess) return e;
+        } else if (D->twist_full[0]) {
+            const uint32_t n = 1u << log2n;
+            if ((e = pow_table(&D->coset_row[0], 1u << D->log_s1, h_pow2k(g, D->log_s2), one, st)) != hipSuccess) return e;   // (g^n2)^j1
+            if ((e = pow_table(&D->coset_row[1], 1u << D->log_s2, h_pow2k(gi, D->log_s1), one, st)) != hipSuccess) return e;  // (g^-n1)^k2
+            uint32_t *gb = nullptr, *gk = nullptr; // g^b, b < n2 and g^-k n^-1, k < n1: folded into the coset twist tables, then dropped
+            if ((e = pow_table(&gb, 1u << D->log_s2, g, one, st)) != hipSuccess) return e;
+            if ((e = pow_table(&gk, 1u << D->log_s1, gi, ninv, st)) != hipSuccess) { (void)hipFree(gb); return e; }
+            for (int inv = 0; inv < 2 && e == hipSuccess; inv++) {
+                if ((e = hipMalloc((void**)&D->coset_twist[inv], (size_t)n * 32)) != hipSuccess) break;
+                ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->coset_twist[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n,
+                                                                       inv ? gk : gb, (uint32_t)inv);
+                e = hipGetLastError();
+            }
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(gb);
+            (void)hipFree(gk);
+            if (e != hipSuccess) return e;
+        }
+    }
     // the tables are published to every later caller, whatever stream it runs on: they must be COMPLETE before get_domain returns
     // (once per domain size; an event per table set would only save this one wait)
     return hipStreamSynchronize(st);
@@ -651,6 +690,8 @@ void free_domain(DomainTables* D)
         if (D->twist_lo[i]) (void)hipFree(D->twist_lo[i]);
         if (D->twist_hi[i]) (void)hipFree(D->twist_hi[i]);
         if (D->twist_full[i]) (void)hipFree(D->twist_full[i]);
+        if (D->coset_row[i]) (void)hipFree(D->coset_row[i]);
+        if (D->coset_twist[i]) (void)hipFree(D->coset_twist[i]);
         if (D->scale_lo[i]) (void)hipFree(D->scale_lo[i]);
         if (D->scale_hi[i]) (void)hipFree(D->scale_hi[i]);
     }
@@ -677,6 +718,12 @@ hipError_t get_domain(int log2n, hipStream_t st, DomainTables** out)
     g_domains[dev * 64 + log2n] = D;
     *out = D;
     return hipSuccess;
+}
+
+bool fused_enabled()
+{
+    static const bool on = [] { const char* e = getenv("BBGPU_NTT_FUSED"); return !e || atoi(e) != 0; }();
+    return on;
 }
 
 // elements per workgroup tile (the fused kernel): 1024 (36 KiB, four workgroups of 256 threads per CU), 2048 (72 KiB, two of 512) or 4096
@@ -706,8 +753,7 @@ template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st
         attr_set = true;
     }
     // sub-transforms of 16 points and more take the kernel with load / store fused into the first / last stage pair (BBGPU_NTT_FUSED=0: A/B)
-    static const bool fused_on = [] { const char* e = getenv("BBGPU_NTT_FUSED"); return !e || atoi(e) != 0; }();
-    if (fused_on && A.log_s >= 4) {
+    if (fused_enabled() && A.log_s >= 4) {
         NttPassArgs B = A;
         B.store_b_fast = (A.out_sb == 1 && A.cols > 1) ? 1u : 0u;
         if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) // double tile: one workgroup of 1024 threads per CU (144 KiB of LDS), rows twice as wide
@@ -727,8 +773,9 @@ hipError_t dispatch(int flags, const NttPassArgs& A, hipStream_t st)
 {
     switch (flags) {
 #define CASE(F) case F: return launch_pass<F>(A, st);
-        CASE(2) CASE(3) CASE(34) CASE(35)                 // pass 1: twist (two-level tables / full table), optionally pre-scaled
+        CASE(2) CASE(3) CASE(34) CASE(35) CASE(98)        // pass 1: twist (two-level tables / full table), optionally pre-scaled (two-level / row table)
         CASE(16) CASE(17) CASE(20) CASE(24) CASE(25) CASE(28) // last pass variants
+        CASE(80) CASE(88) CASE(144)                       // single pass with a row-table pre-scale (16|64, 24|64); post-scale by a row table (16|128)
 #undef CASE
     default: return hipErrorInvalidValue;
     }
@@ -884,7 +931,12 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
         A.tw_sub = D->tw_sub[inverse][0];
         A.log_s = D->log_s1; A.log_b = 0; A.cols = 1; A.log_cols = 0;
         A.in_sa = 1; A.in_sb = 0; A.out_sa = 1; A.out_sb = 0; A.b_fast = 0;
-        e = dispatch(last_flags | (pre ? 1 : 0), A, st);
+        int flags = last_flags | (pre ? 1 : 0);
+        if (fused_enabled() && D->coset_row[0] && (pre || post_table)) { // coset scalings from a per-index table: one multiplication
+            A.row_scale = D->coset_row[post_table ? 1 : 0];
+            flags = pre ? ((last_flags & ~4) | 64) : (16 | 128);
+        }
+        e = dispatch(flags, A, st);
         return e == hipSuccess ? BBGPU_OK : BBGPU_ERR_HIP;
     }
     if (!d_scratch) return BBGPU_ERR_ARG;
@@ -899,7 +951,15 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = n2; A.in_sb = 1; A.out_sa = n2; A.out_sb = 1; A.b_fast = 1;
     A.twist_full = D->twist_full[inverse];
-    if ((e = dispatch(2 | (pre ? 1 : 0) | (A.twist_full ? 32 : 0), A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    int flags1 = 2 | (pre ? 1 : 0) | (A.twist_full ? 32 : 0), flags2 = last_flags;
+    if (fused_enabled() && D->coset_twist[0] && (pre || post_table)) {
+        // coset variants at one extra multiplication per element: the column-constant half of the scaling rides in the coset twist table,
+        // the other half is a row table of pass 1 (coset_fft) or of pass 2's outputs (coset_ifft)
+        A.twist_full = D->coset_twist[post_table ? 1 : 0];
+        if (pre) { A.row_scale = D->coset_row[0]; flags1 = 2 | 32 | 64; }
+        else { flags1 = 2 | 32; flags2 = 16 | 128; }
+    }
+    if ((e = dispatch(flags1, A, st)) != hipSuccess) return BBGPU_ERR_HIP;
     // pass 2: rows (a = j2, b = k1), scratch -> coeffs transposed: X[k1 + n1 * k2]
     A.in = (const uint32_t*)d_scratch;
     A.out = (uint32_t*)d_coeffs;
@@ -910,7 +970,8 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
     A.cols = std::max<uint32_t>(1u, ntt_tile_elems(log2n) >> D->log_s2); if (A.cols > n1) A.cols = n1;
     A.log_cols = 31 - __builtin_clz(A.cols);
     A.in_sa = 1; A.in_sb = n2; A.out_sa = n1; A.out_sb = 1; A.b_fast = 0;
-    if ((e = dispatch(last_flags, A, st)) != hipSuccess) return BBGPU_ERR_HIP;
+    if (flags2 & 128) A.row_scale = D->coset_row[1];
+    if ((e = dispatch(flags2, A, st)) != hipSuccess) return BBGPU_ERR_HIP;
     return BBGPU_OK;
 }
 
