@@ -241,3 +241,27 @@ def test_transcript_writer_matches_the_reference_writer(lib, oracle, tmp_path):
     g2_ours, g2_ref = ours[28 + 64 * (degree - 1):][:256], ref[28 + 64 * num_ref:][:256]
     assert g2_ours == g2_ref                                                                   # G2, x G2
     assert np.array_equal(lib.read_transcript(path, degree), table)
+
+
+def test_bench_input_generator_is_splitmix64():
+    """bench.py's synthetic inputs are splitmix64 from state 0x9e3779b97f4a7c15, 4 outputs per scalar, limb 3 masked to 60 bits"""
+    import bench
+    M = (1 << 64) - 1
+
+    def ref(state, count):
+        out = []
+        for _ in range(count):
+            state = (state + 0x9E3779B97F4A7C15) & M
+            z = state
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            out.append(z ^ (z >> 31))
+        return out
+    got = bench.splitmix64(bench.SPLITMIX_GAMMA, 64)
+    assert [int(v) for v in got] == ref(0x9E3779B97F4A7C15, 64)
+    sc = bench.raw_scalars(16, bench.SPLITMIX_GAMMA)
+    want = ref(0x9E3779B97F4A7C15, 64)
+    for i in range(16):
+        assert [int(v) for v in sc[i]] == want[4 * i:4 * i + 3] + [want[4 * i + 3] & 0x0FFFFFFFFFFFFFFF]
+    assert all(sum(int(v) << (64 * k) for k, v in enumerate(s)) < (1 << 252) for s in sc)
+    assert [int(v) for v in bench.limbs_of(pow(2, 512, bench.FR_MODULUS))] == [0x1BB8E645AE216DA7, 0x53FE3AB1E35C59E3, 0x8C49833D53BB8085, 0x0216D0B17F4E44A5]  # fr.hpp:49-52 r_squared
