@@ -1141,7 +1141,7 @@ int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out)
     const uint32_t jobs = S.jobs;
     int rc = msm_finish_batch(S, res, &g_ctx.last);
     if (rc) return rc;
-    for (uint32_t j = 0; j < jobs; j++) host::g1_to_normalised(res[j], out + 12 * j);
+    host::g1_batch_to_normalised(res, jobs, out); // one inversion for the whole batch
     return BBGPU_OK;
 }
 

@@ -176,5 +176,38 @@ static inline void g1_to_normalised(const Xyzz& p, uint64_t out[12])
     memcpy(out + 8, FQ_ONE.d, 32);
 }
 
+// the same for several points with ONE inversion (Montgomery's trick over the denominators zz * zzz; fields/field.hpp:503-522 is the
+// reference's batch_invert): a prover round's commitments come back together, and a Fermat inversion is ~11 us of host time each
+static inline void g1_batch_to_normalised(const Xyzz* p, size_t count, uint64_t* out /* count x 12 */)
+{
+    Fq den[8], pre[8];
+    if (count > 8) { // not a batch size the library produces: one by one
+        for (size_t i = 0; i < count; i++) g1_to_normalised(p[i], out + 12 * i);
+        return;
+    }
+    Fq run = FQ_ONE;
+    for (size_t i = 0; i < count; i++) {
+        pre[i] = run;
+        den[i] = g1_is_inf(p[i]) ? FQ_ONE : fq_mul(p[i].zz, p[i].zzz);
+        run = fq_mul(run, den[i]);
+    }
+    Fq inv = fq_inv(run);
+    for (size_t i = count; i-- > 0;) {
+        const Fq di = fq_mul(inv, pre[i]); // 1 / den[i]
+        inv = fq_mul(inv, den[i]);
+        uint64_t* o = out + 12 * i;
+        memset(o, 0, 96);
+        if (g1_is_inf(p[i])) {
+            o[7] = 1ULL << 63;
+            continue;
+        }
+        const Fq izz = fq_mul(di, p[i].zzz), izzz = fq_mul(di, p[i].zz);
+        const Fq x = fq_mul(p[i].x, izz), y = fq_mul(p[i].y, izzz);
+        memcpy(o, x.d, 32);
+        memcpy(o + 4, y.d, 32);
+        memcpy(o + 8, FQ_ONE.d, 32);
+    }
+}
+
 } // namespace host
 } // namespace bbgpu
