@@ -110,10 +110,12 @@ def cpu_baseline(table, scalars, expect_xy, ntt_in, ntt_expect, table16, expect1
             tw, r16 = timed(lambda: R.pippenger(sc16, tb16, m, width), 3)
             c1["width_%d_ms" % width] = tw * 1e3
             match = match and bool(np.array_equal(R_norm(R, r16)[:8], expect16_xy))
+        t16b, _ = timed(lambda: R.batched_msm([sc16], [tb16])[0], 3)  # the plumbing config on all granted cores
+        c1["batched_all_cores_ms"] = t16b * 1e3
         # transforms
         ntt = {}
         ntt_match = True
-        for lg, src, expect in ((20, ntt_in, ntt_expect), (22, ntt22_in, ntt22_expect)):
+        for lg, src, expect in ((16, ntt_in[:1 << 16], None), (20, ntt_in, ntt_expect), (22, ntt22_in, ntt22_expect)):
             co = aligned_copy(src)
             R.prepare_domain(1 << lg)
             for kind in ("fft", "coset_fft"):
@@ -126,10 +128,10 @@ def cpu_baseline(table, scalars, expect_xy, ntt_in, ntt_expect, table16, expect1
                     ntt_match = ntt_match and bool(np.array_equal(co, expect[kind]))
         out = {"value": n / tb_s, "unit": "points/s", "cores": threads, "kind": "reference",
                "sample": "medians: 2^20-point MSM 1x pippenger() on 1 thread (%.0f ms, %.3e points/s), 3x batched_scalar_multiplications() on %d threads (%.0f ms); "
-                         "config 1 pippenger(2^16) width 12 / 15 on 1 thread %.0f / %.0f ms; fft / coset_fft on %d threads 2^20 %.1f / %.1f ms, 2^22 %.1f / %.1f ms "
-                         "(each includes the memcpy that restores the input)" % (
-                             t1 * 1e3, n / t1, threads, tb_s * 1e3, c1["width_12_ms"], c1["width_15_ms"], threads, ntt["2^20 fft"]["ms"],
-                             ntt["2^20 coset_fft"]["ms"], ntt["2^22 fft"]["ms"], ntt["2^22 coset_fft"]["ms"]),
+                         "config 1 pippenger(2^16) width 12 / 15 on 1 thread %.0f / %.0f ms, batched on all cores %.1f ms; fft / coset_fft on %d threads 2^16 %.2f / %.2f ms, "
+                         "2^20 %.1f / %.1f ms, 2^22 %.1f / %.1f ms (each includes the memcpy that restores the input)" % (
+                             t1 * 1e3, n / t1, threads, tb_s * 1e3, c1["width_12_ms"], c1["width_15_ms"], c1["batched_all_cores_ms"], threads, ntt["2^16 fft"]["ms"],
+                             ntt["2^16 coset_fft"]["ms"], ntt["2^20 fft"]["ms"], ntt["2^20 coset_fft"]["ms"], ntt["2^22 fft"]["ms"], ntt["2^22 coset_fft"]["ms"]),
                "single_thread_value": n / t1, "single_thread_ms": t1 * 1e3, "all_cores_ms": tb_s * 1e3, "config1_2e16": c1, "ntt": ntt,
                "ntt_value": ntt["2^20 fft"]["elements_per_s"], "gpu_result_bit_exact": match and ntt_match}
     else:
@@ -510,6 +512,7 @@ def main():
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes,
                          "valu": {"bound": "VALU instruction issue of the mixed addition's instruction stream at the measured per-instruction rates",
                                   "floor_ms": issue_floor_ms, "achieved_ms": acc_ms, "frac": issue_floor_ms / acc_ms if acc_ms > 0 else 0.0,
+                                  "fq_multiplications_per_s": share_adds * 10 / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,  # 8M + 2S per mixed addition (report fq mults/s)
                                   "mad_only": {"achieved": share_adds * 1467 / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0, "peak": 467e9 * 64 / 1e12,
                                                "unit": "T lane-mad/s", "frac": (share_adds * 1467 / (acc_ms * 1e-3)) / (467e9 * 64) if acc_ms > 0 else 0.0}}},
             "ntt": {"metric": "Fr radix-2 NTT elements/s at n=2^%d, in place on a device-resident vector" % args.log2n,
