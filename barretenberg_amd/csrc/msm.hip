@@ -31,6 +31,7 @@
 
 #include "bbgpu_internal.h"
 #include "g1.hpp"
+#include "g1_quad.hpp"
 #include "host_g1.hpp"
 
 namespace bbgpu {
@@ -779,6 +780,118 @@ __global__ void __launch_bounds__(FOLD_T) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K5 with quad additions (g1_quad.hpp): the same two kernels, every point spread over the four lanes of a quad.  A workgroup of 256
+// threads = 64 quads sums up to 256 points: each quad first adds its points e, e + 64, ... (<= 3 dependent additions), then a
+// 4-level tree inside the wave (partners move by ds_bpermute: 9 words per lane and level, not 36), then the four wave sums through
+// 576 bytes of LDS and two more levels: <= 9 dependent quad additions of ~1,250 instructions instead of 8 of ~3,700 plus a 36-word
+// LDS round trip and two barriers per level.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int QFOLD_T = 256;
+__device__ __forceinline__ FqN quad_load(const uint32_t* point32, uint32_t l) // coordinate l of a stored XYZZ point (4 x 8 words, canonical Montgomery-261)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(point32 + 8 * l);
+    const uint4 a = q[0], b = q[1];
+    const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+    return FqN(unpack<Fq>(w));
+}
+__device__ __forceinline__ FqN quad_zero()
+{
+    return FqN(fe_zero<Fq>());
+}
+// acc: this lane's coordinate of its quad's partial sum; returns the workgroup's sum in quad 0 of wave 0 (lanes 0..3)
+__device__ __forceinline__ FqN block_quad_sum(FqN acc, uint32_t* sh /* [QFOLD_T / 64][4][NL] */, uint32_t t)
+{
+    const uint32_t l = t & 3, lane = t & 63, wave = t >> 6, qd = lane >> 2;
+    for (uint32_t off = 8; off >= 1; off >>= 1) {
+        FqN o;
+#pragma unroll
+        for (int i = 0; i < NL; i++) o.d[i] = __shfl_down(acc.d[i], off * 4);
+        if (qd < off) acc = quad_add(acc, o, l);
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) sh[(wave * 4 + l) * NL + i] = acc.d[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        constexpr uint32_t NW = QFOLD_T / 64;
+        acc = quad_zero();
+        if (qd < NW) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) acc.d[i] = sh[(qd * 4 + l) * NL + i];
+        }
+        for (uint32_t off = NW >> 1; off >= 1; off >>= 1) {
+            FqN o;
+#pragma unroll
+            for (int i = 0; i < NL; i++) o.d[i] = __shfl_down(acc.d[i], off * 4);
+            if (qd < off) acc = quad_add(acc, o, l);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ void quad_store8(uint32_t* dst8, const uint32_t (&w)[8])
+{
+    uint4* q = reinterpret_cast<uint4*>(dst8);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+__global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_quad_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
+                                                                  uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words)
+{
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __shared__ uint32_t sh[(QFOLD_T / 64) * 4 * NL];
+    const uint32_t g = blockIdx.y, t = threadIdx.x, nb = H * L, l = t & 3, quad = t >> 2;
+    if (zero_out) { // small MSMs: the export slots (infinity = all zero) are cleared here instead of by a fill launch
+        const uint32_t gid = (g * gridDim.x + blockIdx.x) * blockDim.x + t, all = gridDim.y * gridDim.x * blockDim.x;
+        for (uint32_t i = gid; i < zero_words; i += all) zero_out[i] = 0;
+    }
+    const bool row = blockIdx.x < H;
+    const uint32_t idx = row ? blockIdx.x : blockIdx.x - H, count = row ? L : H;
+    FqN acc = quad_zero();
+    bool first = true;
+    for (uint32_t e = quad; e < count; e += QFOLD_T / 4) { // quad-uniform trip count
+        const size_t b = row ? (size_t)idx * L + e : (size_t)e * L + idx;
+        const FqN v = quad_load(buckets + ((size_t)g * nb + b) * 32, l);
+        acc = first ? v : quad_add(acc, v, l);
+        first = false;
+    }
+    acc = block_quad_sum(acc, sh, t);
+    if (t < 4) {
+        uint32_t w[8];
+        to_canonical(acc, w);
+        quad_store8((row ? R + ((size_t)g * H + idx) * 32 : Cc + ((size_t)g * L + idx) * 32) + 8 * l, w);
+    }
+}
+__global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_final_quad_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
+                                                                 uint32_t hbits, uint32_t lbits)
+{
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint32_t sh[(QFOLD_T / 64) * 4 * NL];
+    const uint32_t g = blockIdx.y, t = threadIdx.x, job = blockIdx.x, l = t & 3, quad = t >> 2;
+    const uint32_t H = 1u << hbits, L = 1u << lbits;
+    const uint32_t* src;
+    uint32_t count, slot, k = 0;
+    bool sliced = true;
+    if (job == 0) { src = R + (size_t)g * H * 32; count = H; slot = 0; sliced = false; }
+    else if (job < 1 + hbits) { k = job - 1; src = R + (size_t)g * H * 32; count = H >> 1; slot = 1 + k; }
+    else { k = job - 1 - hbits; src = Cc + (size_t)g * L * 32; count = L >> 1; slot = 32 + k; }
+    FqN acc = quad_zero();
+    bool first = true;
+    for (uint32_t e = quad; e < count; e += QFOLD_T / 4) {
+        const FqN v = quad_load(src + (size_t)(sliced ? insert_one_bit(e, k) : e) * 32, l);
+        acc = first ? v : quad_add(acc, v, l);
+        first = false;
+    }
+    acc = block_quad_sum(acc, sh, t);
+    if (t < 4) {
+        uint32_t w[8];
+        to_canonical(m261_to_m256<Fq>(acc), w); // the host finishes in the reference's Montgomery form (store_xyzz_m256, coordinate by coordinate)
+        quad_store8(out + ((size_t)g * 64 + slot) * 32 + 8 * l, w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------------
 #define HIPCHK(x)                                                                                                      \
@@ -1126,10 +1239,13 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         uint32_t* Cc = scratch + (size_t)G * H * 32;
         uint32_t* dest = fold ? (uint32_t*)ws.h_out : texp; // pinned host memory is device-accessible under the same pointer
         const uint32_t zero_words = G * 64 * 32;
-        msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
+        static const bool quad_tail = [] { const char* e = getenv("BBGPU_QUAD_TAIL"); return !e || atoi(e) != 0; }(); // 0: one point per lane (round 1)
+        if (quad_tail) msm_rowcol_quad_kernel<<<dim3(H + L, G), QFOLD_T, 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
+        else msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
         if (tm) HIPCHK(hipEventRecord(ev[5], st));
         if (!fold) HIPCHK(hipMemsetAsync(texp, 0, (size_t)G * 64 * 128, st)); // unused slots = infinity (zz = 0)
-        msm_final_kernel<<<dim3(1 + P.hbits + P.lbits, G), std::max(H, L), 0, st>>>(Rr, Cc, dest, P.hbits, P.lbits);
+        if (quad_tail) msm_final_quad_kernel<<<dim3(1 + P.hbits + P.lbits, G), QFOLD_T, 0, st>>>(Rr, Cc, dest, P.hbits, P.lbits);
+        else msm_final_kernel<<<dim3(1 + P.hbits + P.lbits, G), std::max(H, L), 0, st>>>(Rr, Cc, dest, P.hbits, P.lbits);
         if (tm) HIPCHK(hipEventRecord(ev[6], st));
     }
     if (!fold) HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));

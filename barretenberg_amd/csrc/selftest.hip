@@ -11,6 +11,7 @@
 
 #include "bbgpu_internal.h"
 #include "g1.hpp"
+#include "g1_quad.hpp"
 
 namespace bbgpu {
 namespace {
@@ -157,6 +158,23 @@ __global__ void selftest_g1_kernel(const uint64_t* p_in, const uint64_t* q_in, u
     st_xyzz(out + 16 * i, R);
 }
 
+// the quad addition of g1_quad.hpp: four lanes per case, lane l holding coordinate l of both operands
+__global__ void selftest_g1_quad_kernel(const uint64_t* p_in, const uint64_t* q_in, uint64_t* out, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 2;
+    const uint32_t l = (uint32_t)t & 3u;
+    if (i >= n) return; // whole quads leave together
+    Xyzz P, Q;
+    ld_jacobian(P, p_in + 12 * i);
+    ld_jacobian(Q, q_in + 12 * i);
+    const FqN pl = l == 0 ? P.x : (l == 1 ? P.y : (l == 2 ? P.zz : P.zzz));
+    const FqN ql = l == 0 ? Q.x : (l == 1 ? Q.y : (l == 2 ? Q.zz : Q.zzz));
+    const FqN r = quad_add(pl, ql, l);
+    uint32_t w[8];
+    to_canonical(m261_to_m256<Fq>(r), w);
+    for (int k = 0; k < 4; k++) out[16 * i + 4 * l + k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);
+}
+
 int run(const void* a, size_t a_bytes, const void* b, size_t b_bytes, void* out, size_t out_bytes, int n, const std::function<void(uint64_t*, uint64_t*, uint64_t*)>& launch)
 {
     uint64_t *da = nullptr, *db = nullptr, *dout = nullptr;
@@ -207,7 +225,8 @@ int bbgpu_selftest_g1(int op, const uint64_t* p, const uint64_t* q, size_t n, ui
         return BBGPU_ERR_HIP;
     }
     return run(p, n * 96, q, n * 96, out, n * 128, (int)n, [&](uint64_t* dp, uint64_t* dq, uint64_t* dout) {
-        selftest_g1_kernel<<<(int)((n + 63) / 64), 64>>>(dp, dq, dout, (int)n, op);
+        if (op == BBGPU_SELFTEST_G1_QUAD_ADD) selftest_g1_quad_kernel<<<(int)((4 * n + 63) / 64), 64>>>(dp, dq, dout, (int)n);
+        else selftest_g1_kernel<<<(int)((n + 63) / 64), 64>>>(dp, dq, dout, (int)n, op);
     });
 }
 

@@ -273,7 +273,8 @@ enum {
     BBGPU_SELFTEST_G1_ADD = 1,       /* p + q                                                      g1::add, :324-448 */
     BBGPU_SELFTEST_G1_DBL = 2,       /* 2 p                                                        g1::dbl, :153-217 */
     BBGPU_SELFTEST_G1_DBL_AFFINE = 3,/* 2 p for an affine p (the P + P branch of the mixed addition) */
-    BBGPU_SELFTEST_G1_MADD_NEG = 4   /* p - (q.x, q.y): the conditionally negated operand the bucket accumulation feeds (group_impl_asm.tcc:71-153) */
+    BBGPU_SELFTEST_G1_MADD_NEG = 4,  /* p - (q.x, q.y): the conditionally negated operand the bucket accumulation feeds (group_impl_asm.tcc:71-153) */
+    BBGPU_SELFTEST_G1_QUAD_ADD = 5   /* p + q by the four-lanes-per-point addition of the bucket reduction (csrc/g1_quad.hpp) */
 };
 /* field: 0 = fq, 1 = fr; a, b, out: n x 4 limbs */
 int bbgpu_selftest_field(int field, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);

@@ -128,7 +128,7 @@ def test_device_g1_ops_vs_reference_outputs(gpu, oracle, golden):
     q = np.stack([limbs(c["scalar_mul_G"]) for c in cases])
     m = np.stack([limbs(c["mixed_add"]) for c in cases])
     a = np.stack([limbs(c["add"]) for c in cases])
-    for op, p_in, q_in, key in (("madd", acc, q, "mixed_add"), ("add", m, acc, "add"), ("dbl", a, a, "dbl")):
+    for op, p_in, q_in, key in (("madd", acc, q, "mixed_add"), ("add", m, acc, "add"), ("quad_add", m, acc, "add"), ("dbl", a, a, "dbl")):
         got = gpu.selftest_g1(op, p_in, q_in)
         for c, r in zip(cases, got):
             assert np.array_equal(_norm_xyzz(oracle, r), oracle.g1_normalize(limbs(c[key]))), (op, c["scalar"])
@@ -189,7 +189,22 @@ def test_device_g1_exceptional_cases(gpu, oracle, golden):
     Q = np.roll(A, 1, axis=0)
     for r, j, n in zip(gpu.selftest_g1("madd_neg", P, Q), jac, np.roll(N, 1, axis=0)):
         assert np.array_equal(_norm_xyzz(oracle, r), oracle.g1_normalize(oracle.g1_mixed_add(j, n[:8])))
-    # full addition: P + P, P + (-P), inf + P, P + inf, inf + inf
+    # full addition: P + P, P + (-P), inf + P, P + inf, inf + inf -- by the one-lane add() and by the four-lane quad addition of the bucket reduction
+    for op in ("add", "quad_add"):
+        for r, w in zip(gpu.selftest_g1(op, P, A), want_dbl):
+            assert np.array_equal(_norm_xyzz(oracle, r), w), op
+        for r in gpu.selftest_g1(op, P, N):
+            assert np.array_equal(_norm_xyzz(oracle, r), _inf()), op
+        for r, a in zip(gpu.selftest_g1(op, INF, P), aff):
+            assert np.array_equal(_norm_xyzz(oracle, r), a), op
+        for r, a in zip(gpu.selftest_g1(op, P, INF), aff):
+            assert np.array_equal(_norm_xyzz(oracle, r), a), op
+        for r in gpu.selftest_g1(op, INF, INF):
+            assert np.array_equal(_norm_xyzz(oracle, r), _inf()), op
+        # two different points, in both orders, mixed with exceptional quads in the same wave
+        Qr = np.roll(P, 1, axis=0)
+        for r, j, k in zip(gpu.selftest_g1(op, P, Qr), jac, np.roll(np.stack(jac), 1, axis=0)):
+            assert np.array_equal(_norm_xyzz(oracle, r), oracle.g1_normalize(oracle.g1_add(j, k))), op
     for r, w in zip(gpu.selftest_g1("add", P, A), want_dbl):
         assert np.array_equal(_norm_xyzz(oracle, r), w)
     for r in gpu.selftest_g1("add", P, N):
