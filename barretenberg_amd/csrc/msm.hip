@@ -287,6 +287,24 @@ template <class DT> __device__ __forceinline__ int load_digit(const DT* __restri
         return dg[i];
     }
 }
+// eight consecutive digits of one window, first index a multiple of 8 (one 16-byte load + one byte of sign bits): the sort passes are
+// chains of load -> LDS atomic -> store per lane, i.e. bound by the number of dependent global loads a lane issues
+template <class DT> __device__ __forceinline__ void load_digits8(const DT* __restrict__ dg, const unsigned long long* __restrict__ sg, uint32_t i8, int (&d)[8])
+{
+    const uint4 q = *reinterpret_cast<const uint4*>(dg + i8);
+    const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+    if constexpr (DigitTraits<DT>::wide) {
+        const uint32_t sb = reinterpret_cast<const uint8_t*>(sg)[i8 >> 3];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int u = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+            d[k] = ((sb >> k) & 1u) ? -u - 1 : u;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+    }
+}
 template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, DT* __restrict__ digits_all, unsigned long long* __restrict__ signs_all,
                                                                uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we)
 {
@@ -352,14 +370,28 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
     lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
-    for (uint32_t k = 0; k < wpg; k++) {
-        const DT* dg = digits + (size_t)(win0 + wl * wpg + k) * n;
-        const unsigned long long* sg = signs + (size_t)(win0 + wl * wpg + k) * ((n + 63) >> 6);
-        // a row-range share (msm_issue_rows) owns only points >= first_i0 of its first window and < last_i1 of its last one
-        const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
-        for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
-            const int d = load_digit<DT>(dg, sg, i);
-            if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
+    const uint32_t s64 = (n + 63) >> 6;
+    if ((n & 7u) == 0) { // rows are 16-byte aligned: 8 digits per load, the (window, block of 8) pairs of the slice dealt round-robin to the lanes
+        const uint32_t lo8 = lo & ~7u, bpw = lo < hi ? (((hi + 7u) & ~7u) - lo8) >> 3 : 0u;
+        for (uint32_t u = threadIdx.x; u < wpg * bpw; u += SORT_THREADS) {
+            const uint32_t k = u / bpw, i8 = lo8 + (u - k * bpw) * 8;
+            const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
+            int d[8];
+            load_digits8<DT>(digits + (size_t)(win0 + wl * wpg + k) * n, signs + (size_t)(win0 + wl * wpg + k) * s64, i8, d);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (d[j] && i8 + j >= klo && i8 + j < khi) atomicAdd(&lh[(uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1) >> lb], 1u);
+        }
+    } else {
+        for (uint32_t k = 0; k < wpg; k++) {
+            const DT* dg = digits + (size_t)(win0 + wl * wpg + k) * n;
+            const unsigned long long* sg = signs + (size_t)(win0 + wl * wpg + k) * s64;
+            // a row-range share (msm_issue_rows) owns only points >= first_i0 of its first window and < last_i1 of its last one
+            const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
+            for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
+                const int d = load_digit<DT>(dg, sg, i);
+                if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
+            }
         }
     }
     __syncthreads();
@@ -443,10 +475,31 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
     __syncthreads();
     const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
     const uint32_t lomask = (1u << lb) - 1;
+    const uint32_t s64 = (n + 63) >> 6;
+    if ((n & 7u) == 0) { // as in sortA_hist_kernel (the two kernels must visit exactly the same entries; their order inside a bin is free)
+        const uint32_t lo8 = lo & ~7u, bpw = lo < hi ? (((hi + 7u) & ~7u) - lo8) >> 3 : 0u;
+        for (uint32_t u = threadIdx.x; u < wpg * bpw; u += SORT_THREADS) {
+            const uint32_t k = u / bpw, i8 = lo8 + (u - k * bpw) * 8;
+            const uint32_t wabs = win0 + wl * wpg + k;
+            const uint32_t row = (wabs % windows_per_job) * idx_stride;
+            const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
+            int d[8];
+            load_digits8<DT>(digits + (size_t)wabs * n, signs + (size_t)wabs * s64, i8, d);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (d[j] && i8 + j >= klo && i8 + j < khi) {
+                    const uint32_t b = (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1);
+                    const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
+                    tmp[pos] = (row + i8 + j) | ((b & lomask) << 24) | (d[j] < 0 ? 0x80000000u : 0u);
+                }
+            }
+        }
+        return;
+    }
     for (uint32_t k = 0; k < wpg; k++) {
         const uint32_t wabs = win0 + wl * wpg + k;
         const DT* dg = digits + (size_t)wabs * n;
-        const unsigned long long* sg = signs + (size_t)wabs * ((n + 63) >> 6);
+        const unsigned long long* sg = signs + (size_t)wabs * s64;
         const uint32_t row = (wabs % windows_per_job) * idx_stride; // row of the pre-shifted table (0 without tables); batches repeat the windows per job
         const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
         for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
@@ -474,22 +527,48 @@ __global__ void __launch_bounds__(SORT_THREADS) sortB_kernel(const uint32_t* __r
     const uint32_t end = (bin + 1 < bins) ? bases[wl] + binstart[(size_t)wl * bins + bin + 1] : bases[wl + 1];
     if (t < 128) cnt[t] = 0;
     __syncthreads();
-    for (uint32_t e = start + t; e < end; e += blockDim.x) atomicAdd(&cnt[(tmp[e] >> 24) & 0x7f], 1u);
-    __syncthreads();
-    if (t == 0) { // 128 counters: a serial scan is cheaper than a barrier ladder
-        uint32_t run = start;
-        for (uint32_t k = 0; k < nlo; k++) {
-            cur[k] = run;
-            run += cnt[k];
+    // eight independent loads per lane and trip (a lane's entries are blockDim apart: every load of the wave is one coalesced run)
+    constexpr int UB = 8;
+    for (uint32_t e0 = start + t; e0 < end; e0 += UB * blockDim.x) {
+        uint32_t v[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const uint32_t e = e0 + k * blockDim.x;
+            v[k] = e < end ? tmp[e] : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < UB; k++)
+            if (e0 + k * blockDim.x < end) atomicAdd(&cnt[(v[k] >> 24) & 0x7f], 1u);
+    }
+    __syncthreads();
+    if (t < 64) { // exclusive scan of the <= 128 counters by one wave, two counters per lane
+        const uint32_t a = cnt[2 * t], b2 = cnt[2 * t + 1], sum = a + b2;
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if ((int)t >= off) incl += o;
+        }
+        cur[2 * t] = start + incl - sum;
+        cur[2 * t + 1] = start + incl - sum + a;
     }
     __syncthreads();
     if (t < nlo) gstart[(size_t)wl * nb + (size_t)bin * nlo + t] = cur[t];
     __syncthreads();
-    for (uint32_t e = start + t; e < end; e += blockDim.x) {
-        const uint32_t v = tmp[e];
-        const uint32_t pos = atomicAdd(&cur[(v >> 24) & 0x7f], 1u);
-        sorted[pos] = v & 0x80ffffffu;
+    for (uint32_t e0 = start + t; e0 < end; e0 += UB * blockDim.x) {
+        uint32_t v[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const uint32_t e = e0 + k * blockDim.x;
+            v[k] = e < end ? tmp[e] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            if (e0 + k * blockDim.x < end) {
+                const uint32_t pos = atomicAdd(&cur[(v[k] >> 24) & 0x7f], 1u);
+                sorted[pos] = v[k] & 0x80ffffffu;
+            }
+        }
     }
 }
 
@@ -836,6 +915,49 @@ __device__ __forceinline__ void quad_store8(uint32_t* dst8, const uint32_t (&w)[
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// K4m with quad additions: 2^logQ quads share a bucket; quad j adds partials j, j + Q, ... (coordinate l of a raw partial = 9 lazy limbs at
+// word 9 l), the quads of a bucket are combined by a shuffle tree and quad 0 writes the bucket canonical, 8 words per lane.  The chain is
+// ~ceil(count / Q) + logQ quad additions of ~1,250 instructions: at 2^20 (4 partials per bucket, Q = 1) 3 quad additions instead of
+// 3 full ones, at 2^16 (9.5 partials, Q = 4) 4 instead of 6.
+__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_quad_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+                                                                   uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
+                                                                   uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logQ)
+{
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, l = t & 3, quad = t >> 2;
+    const uint32_t Q = 1u << logQ, b = quad >> logQ, j = quad & (Q - 1);
+    if (b >= total_buckets) return; // whole bucket groups leave together (4 Q lanes, aligned inside a wave)
+    const uint32_t s = gstart[b], e = gstart[b + 1];
+    FqN acc = quad_zero();
+    if (e > s) {
+        const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
+        if (t1 - t0 >= MERGE_LIGHT) { // heavy[0] = count, heavy[1..] = bucket ids
+            if (j == 0 && l == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
+            return;
+        }
+        bool first = true;
+        for (uint32_t k = t0 + j; k <= t1; k += Q) { // quad-uniform trip count
+            const uint32_t* src = partials + (size_t)(b + k) * RAW_WORDS + NL * l;
+            FqN q;
+#pragma unroll
+            for (int i = 0; i < NL; i++) q.d[i] = src[i];
+            acc = first ? q : quad_add(acc, q, l);
+            first = false;
+        }
+    }
+    for (uint32_t off = Q >> 1; off >= 1; off >>= 1) {
+        FqN o;
+#pragma unroll
+        for (int i = 0; i < NL; i++) o.d[i] = __shfl_down(acc.d[i], off * 4);
+        if (j < off) acc = quad_add(acc, o, l);
+    }
+    if (j == 0) {
+        uint32_t w[8];
+        to_canonical(acc, w);
+        quad_store8(buckets + (size_t)b * 32 + 8 * l, w);
+    }
+}
+
 __global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_quad_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
                                                                   uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words)
 {
@@ -964,6 +1086,8 @@ static uint32_t chunk_len(size_t n, uint32_t nw)
         waves = 1;
         if (const char* e = getenv("BBGPU_ACC_WAVES")) waves = std::min(16, std::max(1, atoi(e)));
     }
+    static const int forced = [] { const char* e = getenv("BBGPU_CHUNK"); return e ? std::max((int)MIN_CHUNK, atoi(e)) : 0; }(); // tuning knob (small MSMs)
+    if (forced) return (uint32_t)std::max<uint64_t>(forced, (m + ((uint64_t)1 << 24) - 1) >> 24);
     const uint64_t cap = (uint64_t)acc_capacity_lanes() * (uint64_t)waves;
     uint32_t ch = (uint32_t)((m + cap - 1) / cap);
     return ch < MIN_CHUNK ? MIN_CHUNK : ch;
@@ -1224,6 +1348,19 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         S.acc_seq = 0;
     }
     if (!fold) HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
+    static const bool quad_tail = [] { const char* e = getenv("BBGPU_QUAD_TAIL"); return !e || atoi(e) != 0; }(); // 0: one point per lane (round 1)
+    static const int quad_merge = [] { const char* e = getenv("BBGPU_QUAD_MERGE"); return e ? atoi(e) : 1; }(); // tuning knob: 0 off, 1 on, 2.. = 1 + forced logQ
+    // The merge of a full-size MSM keeps every SIMD busy with one point per lane (2^20: 196,608 additions, 42 us either way; a quad addition is
+    // 4 x 1,250 lane-instructions against 3,700); quads pay where the lanes do not fill the chip: a 2-of-17-window share of a 2^16-point MSM
+    // 0.200 -> 0.183 ms latency, 0.102 -> 0.094 ms per step (tools/msm_ab.py, one box).
+    if (quad_tail && (quad_merge > 1 || (quad_merge == 1 && (uint64_t)n * nw <= ((uint64_t)1 << 19)))) {
+        // quads per bucket: about half the expected number of partials, within one resident wave of tail workgroups (~2^18 lanes)
+        uint32_t logQ = 0;
+        while ((2u << logQ) < avg_partials && logQ < 4 && ((uint64_t)total_buckets << (logQ + 3)) <= ((uint64_t)1 << 18)) logQ++;
+        if (quad_merge > 1) logQ = std::min(4, quad_merge - 2);
+        msm_merge_quad_kernel<<<(uint32_t)((((uint64_t)total_buckets << (logQ + 2)) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch,
+                                                                                                                                  std::max(6u, 8u << logQ), logQ);
+    } else
     msm_merge_kernel<<<(uint32_t)((((uint64_t)total_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
                                                                                                                      total_buckets, ch, merge_light, logG);
     msm_merge_heavy_kernel<<<256, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
@@ -1239,7 +1376,6 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         uint32_t* Cc = scratch + (size_t)G * H * 32;
         uint32_t* dest = fold ? (uint32_t*)ws.h_out : texp; // pinned host memory is device-accessible under the same pointer
         const uint32_t zero_words = G * 64 * 32;
-        static const bool quad_tail = [] { const char* e = getenv("BBGPU_QUAD_TAIL"); return !e || atoi(e) != 0; }(); // 0: one point per lane (round 1)
         if (quad_tail) msm_rowcol_quad_kernel<<<dim3(H + L, G), QFOLD_T, 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
         else msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
         if (tm) HIPCHK(hipEventRecord(ev[5], st));
