@@ -513,6 +513,91 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
     }
 }
 
+// Pass A with the scatter staged through LDS (see sortB_staged_kernel for why): a tile = one 16-byte digit load per lane (<= 8,192 entries)
+// is ranked by bin with LDS atomics, the tile histogram is scanned by the workgroup, the entries are laid out bin by bin in LDS (with
+// their bin beside them: the entry word has no room for it) and written out with consecutive lanes on consecutive addresses.
+// Rows must be 16-byte aligned (n % 8 == 0); visits exactly the entries sortA_hist_kernel counted.
+template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) sortA_scatter_staged_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, const uint32_t* __restrict__ cursorsA,
+                                                                          const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
+                                                                          uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
+                                                                          uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
+                                                                          uint32_t idx_stride, uint32_t windows_per_job, uint32_t first_i0, uint32_t last_i1)
+{
+    FRONT_PRIO();
+    constexpr uint32_t TILE = SORT_THREADS * 8;
+    __shared__ uint32_t lc[SORT_THREADS];   // next global position per bin
+    __shared__ uint32_t th[SORT_THREADS];   // tile histogram, then first slot of the bin in the tile buffer
+    __shared__ uint32_t dlt[SORT_THREADS];  // global position - slot
+    __shared__ uint32_t wsum[SORT_THREADS / 64 + 1];
+    __shared__ uint32_t buf[TILE];
+    __shared__ uint16_t bbin[TILE];
+    const uint32_t s = blockIdx.x, wl = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    lc[t] = t < bins ? cursorsA[((size_t)wl * slices + s) * bins + t] + binstart[(size_t)wl * bins + t] + bases[wl] : 0u;
+    const uint32_t lo = s * slice_len, hi = min(n, lo + slice_len);
+    const uint32_t lomask = (1u << lb) - 1;
+    const uint32_t s64 = (n + 63) >> 6;
+    const uint32_t lo8 = lo & ~7u, bpw = lo < hi ? (((hi + 7u) & ~7u) - lo8) >> 3 : 0u;
+    const uint32_t total_u = wpg * bpw;
+    for (uint32_t u0 = 0; u0 < total_u; u0 += SORT_THREADS) { // workgroup-uniform trip count
+        th[t] = 0;
+        __syncthreads();
+        uint32_t ent[8], bn[8], rk[8];
+        const uint32_t u = u0 + t;
+#pragma unroll
+        for (int j = 0; j < 8; j++) bn[j] = 0xffffffffu;
+        if (u < total_u) {
+            const uint32_t k = u / bpw, i8 = lo8 + (u - k * bpw) * 8;
+            const uint32_t wabs = win0 + wl * wpg + k;
+            const uint32_t row = (wabs % windows_per_job) * idx_stride;
+            const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
+            int d[8];
+            load_digits8<DT>(digits + (size_t)wabs * n, signs + (size_t)wabs * s64, i8, d);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (d[j] && i8 + j >= klo && i8 + j < khi) {
+                    const uint32_t b = (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1);
+                    bn[j] = b >> lb;
+                    ent[j] = (row + i8 + j) | ((b & lomask) << 24) | (d[j] < 0 ? 0x80000000u : 0u);
+                    rk[j] = atomicAdd(&th[bn[j]], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the tile histogram over the bins (one value per lane; th is zero beyond `bins`)
+        const uint32_t c = th[t];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+        const uint32_t excl = before + incl - c;
+        th[t] = excl;
+        const uint32_t g = lc[t];
+        dlt[t] = g - excl;
+        lc[t] = g + c;
+        if (t == SORT_THREADS - 1) wsum[SORT_THREADS / 64] = excl + c; // entries in this tile
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (bn[j] != 0xffffffffu) {
+                const uint32_t slot = th[bn[j]] + rk[j];
+                buf[slot] = ent[j];
+                bbin[slot] = (uint16_t)bn[j];
+            }
+        }
+        __syncthreads();
+        const uint32_t tile_n = wsum[SORT_THREADS / 64];
+        for (uint32_t x = t; x < tile_n; x += SORT_THREADS) tmp[dlt[bbin[x]] + x] = buf[x];
+        // the next trip's barriers order these reads before wsum / buf / dlt are rewritten (all written after its second barrier;
+        // th, cleared before its first barrier, is not read here)
+    }
+}
+
 // pass B: one workgroup per (bin, window): counting sort by `lo`, emits the final entries and the global bucket starts
 __global__ void __launch_bounds__(SORT_THREADS) sortB_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binstart,
                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ sorted, uint32_t* __restrict__ gstart,
@@ -569,6 +654,98 @@ __global__ void __launch_bounds__(SORT_THREADS) sortB_kernel(const uint32_t* __r
                 sorted[pos] = v[k] & 0x80ffffffu;
             }
         }
+    }
+}
+
+// Pass B with the scatter staged through LDS.  A lane's `sorted[pos] = v` of sortB_kernel is a 4-byte write to one of 128 runs: 64 requests
+// per wave store, and the L2 takes ~128 requests per clock chip-wide -- 15.7M entries = 58 us of request issue alone (measured 74 us).
+// Here a tile of 8 entries per lane is ranked by sub-bucket in LDS (LDS atomics), laid out sub-bucket by sub-bucket in a 32 KiB
+// buffer, and written out with consecutive lanes on consecutive addresses: runs of ~64 entries = two full 128-byte lines per sub-bucket and tile.
+template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_staged_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binstart,
+                                                                                        const uint32_t* __restrict__ bases, uint32_t* __restrict__ sorted,
+                                                                                        uint32_t* __restrict__ gstart, uint32_t bins, uint32_t lb, uint32_t nb)
+{
+    FRONT_PRIO();
+    constexpr int UB = 8;
+    constexpr uint32_t TILE = THREADS * UB;
+    __shared__ uint32_t cnt[128];   // entries per sub-bucket: whole bin, then per tile
+    __shared__ uint32_t cur[128];   // next global position per sub-bucket
+    __shared__ uint32_t toff[128];  // first slot of the sub-bucket in the tile buffer
+    __shared__ uint32_t dlt[128];   // global position - slot
+    __shared__ uint32_t buf[TILE];
+    const uint32_t bin = blockIdx.x, wl = blockIdx.y, t = threadIdx.x;
+    const uint32_t nlo = 1u << lb;
+    const uint32_t start = bases[wl] + binstart[(size_t)wl * bins + bin];
+    const uint32_t end = (bin + 1 < bins) ? bases[wl] + binstart[(size_t)wl * bins + bin + 1] : bases[wl + 1];
+    if (t < 128) cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t e0 = start + t; e0 < end; e0 += TILE) {
+        uint32_t v[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const uint32_t e = e0 + k * THREADS;
+            v[k] = e < end ? tmp[e] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++)
+            if (e0 + k * THREADS < end) atomicAdd(&cnt[(v[k] >> 24) & 0x7f], 1u);
+    }
+    __syncthreads();
+    if (t < 64) { // exclusive scan of the <= 128 counters by one wave, two counters per lane
+        const uint32_t a = cnt[2 * t], b2 = cnt[2 * t + 1], sum = a + b2;
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if ((int)t >= off) incl += o;
+        }
+        cur[2 * t] = start + incl - sum;
+        cur[2 * t + 1] = start + incl - sum + a;
+    }
+    __syncthreads();
+    if (t < nlo) gstart[(size_t)wl * nb + (size_t)bin * nlo + t] = cur[t];
+    for (uint32_t base = start; base < end; base += TILE) { // workgroup-uniform trip count
+        if (t < 128) cnt[t] = 0;
+        __syncthreads();
+        uint32_t v[UB], rk[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const uint32_t e = base + k * THREADS + t;
+            v[k] = e < end ? tmp[e] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++)
+            rk[k] = (base + k * THREADS + t < end) ? atomicAdd(&cnt[(v[k] >> 24) & 0x7f], 1u) : 0u;
+        __syncthreads();
+        if (t < 64) {
+            const uint32_t a = cnt[2 * t], b2 = cnt[2 * t + 1], sum = a + b2;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if ((int)t >= off) incl += o;
+            }
+            const uint32_t x0 = incl - sum, x1 = x0 + a;
+            toff[2 * t] = x0;
+            toff[2 * t + 1] = x1;
+            const uint32_t c0 = cur[2 * t], c1 = cur[2 * t + 1];
+            dlt[2 * t] = c0 - x0;
+            dlt[2 * t + 1] = c1 - x1;
+            cur[2 * t] = c0 + a;
+            cur[2 * t + 1] = c1 + b2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < UB; k++)
+            if (base + k * THREADS + t < end) buf[toff[(v[k] >> 24) & 0x7f] + rk[k]] = v[k];
+        __syncthreads();
+        const uint32_t tile_n = min(TILE, end - base);
+        for (uint32_t x = t; x < tile_n; x += THREADS) {
+            const uint32_t w = buf[x];
+            sorted[dlt[(w >> 24) & 0x7f] + x] = w & 0x80ffffffu;
+        }
+        // the next trip's first barrier (after clearing cnt) orders these reads of buf / dlt before they are overwritten:
+        // buf and dlt are written only after that trip's second barrier
     }
 }
 
@@ -1316,11 +1493,20 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
     sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
     sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
+    static const int staged = [] { const char* e = getenv("BBGPU_SORT_STAGED"); return e ? atoi(e) : 3; }(); // tuning knob: bit 0 pass B, bit 1 pass A
+    if ((staged & 2) && (P.n & 7u) == 0) {
+        if (wide) sortA_scatter_staged_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
+                                                                                  slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
+        else sortA_scatter_staged_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
+                                                                            slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
+    } else
     if (wide) sortA_scatter_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
                                                                    slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
     else sortA_scatter_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
                                                                    slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
-    sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
+    if (!(staged & 1)) sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
+    else if (table) sortB_staged_kernel<SORT_THREADS><<<dim3(sort_bins, G), SORT_THREADS, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
+    else sortB_staged_kernel<256><<<dim3(sort_bins, G), 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     if (tm_acc) HIPCHK(hipEventRecord(ev[2], st));
     // K4 + K4m
     const uint32_t total_buckets = G * P.nb;
