@@ -73,6 +73,8 @@ class PlonkProver {
     int log2n = 0;
     int srs = -1;
     hipStream_t st = nullptr;
+    hipStream_t st_msm = nullptr;   // the commitments' own queue, ordered after `st` by an event instead of a host round trip
+    hipEvent_t scalars_ready = nullptr;
     poly::Scratch scratch;
     std::vector<void*> allocs;
 
@@ -129,6 +131,10 @@ class PlonkProver {
         scratch.release();
         if (st) (void)hipStreamDestroy(st);
         st = nullptr;
+        if (st_msm) (void)hipStreamDestroy(st_msm);
+        st_msm = nullptr;
+        if (scalars_ready) (void)hipEventDestroy(scalars_ready);
+        scalars_ready = nullptr;
     }
     template <class T> int dalloc(T** p, size_t bytes)
     {
@@ -143,6 +149,8 @@ class PlonkProver {
         log2n = ilog2(n);
         srs = srs_handle;
         HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&st_msm, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&scalars_ready, hipEventDisableTiming));
         const size_t fb = n * 32;
         const uint64_t* hw[3] = { c->w_l, c->w_r, c->w_o };
         const uint32_t* hm[3] = { c->sigma_1_mapping, c->sigma_2_mapping, c->sigma_3_mapping };
@@ -240,33 +248,54 @@ class PlonkProver {
         return BBGPU_OK;
     }
     // commitments of `count` <= 3 resident coefficient vectors of n scalars: one batched pass (bbgpu_msm_g1_device_batch_async);
-    // without window tables on the SRS, side-by-side single MSMs
-    int commit(const uint64_t* const* scalars, int count, uint64_t (*out)[8])
+    // without window tables on the SRS, side-by-side single MSMs.  Split in two so that work of the NEXT round which does not depend
+    // on this round's challenge can be enqueued on our stream in between: a 2^16-point batch is a ~0.4 ms chain of mostly
+    // latency-bound launches on the MSM's own queues, beside which transforms run almost for free.
+    struct PendingCommit {
+        int count = 0, ticket = -1, tk[3] = { -1, -1, -1 };
+        bool batched = true;
+        double t0 = 0.0;
+    };
+    int commit_begin(const uint64_t* const* scalars, int count, PendingCommit& P)
     {
-        const double t0 = now_ms();
-        HIPCHK(hipStreamSynchronize(st)); // the scalars are produced on our stream; the MSM slots run on their own
+        P = PendingCommit();
+        P.t0 = now_ms();
+        P.count = count;
+        // the scalars are produced on `st`; the commitments run on their own queue behind an event (no host round trip)
+        HIPCHK(hipEventRecord(scalars_ready, st));
+        HIPCHK(hipStreamWaitEvent(st_msm, scalars_ready, 0));
+        P.ticket = bbgpu_msm_g1_device_batch_async(srs, 0, scalars, count, n, st_msm);
+        if (P.ticket >= 0) return BBGPU_OK;
+        if (P.ticket != BBGPU_ERR_ARG) return P.ticket;
+        P.batched = false;
+        const int W = bbgpu_srs_num_windows(srs, n);
+        if (W < 0) return W;
+        for (int i = 0; i < count; i++) {
+            P.tk[i] = bbgpu_msm_g1_device_async(srs, 0, scalars[i], n, 0, W, st_msm);
+            if (P.tk[i] < 0) return P.tk[i];
+        }
+        return BBGPU_OK;
+    }
+    int commit_end(PendingCommit& P, uint64_t (*out)[8])
+    {
         uint64_t res[4 * 12];
-        int ticket = bbgpu_msm_g1_device_batch_async(srs, 0, scalars, count, n, nullptr);
-        if (ticket >= 0) {
-            RC(bbgpu_msm_g1_batch_wait(ticket, res));
-            for (int i = 0; i < count; i++) memcpy(out[i], res + 12 * i, 64); // normalised: x, y canonical
-        } else if (ticket == BBGPU_ERR_ARG) {
-            const int W = bbgpu_srs_num_windows(srs, n);
-            if (W < 0) return W;
-            int tk[3] = { -1, -1, -1 };
-            for (int i = 0; i < count; i++) {
-                tk[i] = bbgpu_msm_g1_device_async(srs, 0, scalars[i], n, 0, W, nullptr);
-                if (tk[i] < 0) return tk[i];
-            }
-            for (int i = 0; i < count; i++) {
-                RC(bbgpu_msm_g1_wait(tk[i], res));
+        if (P.batched) {
+            RC(bbgpu_msm_g1_batch_wait(P.ticket, res));
+            for (int i = 0; i < P.count; i++) memcpy(out[i], res + 12 * i, 64); // normalised: x, y canonical
+        } else {
+            for (int i = 0; i < P.count; i++) {
+                RC(bbgpu_msm_g1_wait(P.tk[i], res));
                 memcpy(out[i], res, 64);
             }
-        } else {
-            return ticket;
         }
-        timing[1] += now_ms() - t0;
+        timing[1] += now_ms() - P.t0;
         return BBGPU_OK;
+    }
+    int commit(const uint64_t* const* scalars, int count, uint64_t (*out)[8])
+    {
+        PendingCommit P;
+        RC(commit_begin(scalars, count, P));
+        return commit_end(P, out);
     }
     // challenge.hpp:15-62: commitments / evaluations enter the transcript out of Montgomery form
     static void put_point(std::vector<uint64_t>& buf, const uint64_t p[8])
@@ -349,7 +378,12 @@ class PlonkProver {
     {
         const uint64_t* sc[3] = { w[0], w[1], w[2] };
         uint64_t out[3][8];
-        RC(commit(sc, 3, out));
+        PendingCommit P;
+        RC(commit_begin(sc, 3, P));
+        // beside the commitments: the wires on the 4n coset (prover.cpp:418-425) need no challenge
+        for (int k = 0; k < 3; k++) RC(poly::copy_pad(w_fft[k], w[k], n, 4 * n, st));
+        RC(ntt_batch(w_fft[0], 4 * n, 3, BBGPU_COSET_FFT));
+        RC(commit_end(P, out));
         memcpy(proof.W_L, out[0], 64);
         memcpy(proof.W_R, out[1], 64);
         memcpy(proof.W_O, out[2], 64);
@@ -388,7 +422,14 @@ class PlonkProver {
     {
         const uint64_t* sc[1] = { z };
         uint64_t out[1][8];
-        RC(commit(sc, 1, out));
+        PendingCommit P;
+        RC(commit_begin(sc, 1, P));
+        // beside the commitment: the permutation polynomials need beta and gamma only (prover.cpp:245-247, :253-276)
+        RC(copy(sigma[0], sigma_lagrange[0], 3 * n));
+        RC(ntt_batch(sigma[0], n, 3, BBGPU_IFFT_WITH_CONSTANT, &challenges.beta));
+        for (int k = 0; k < 3; k++) RC(poly::sigma_prepare(s_fft[k], sigma[k], w[k], n, 4 * n, challenges.gamma, st));
+        RC(ntt_batch(s_fft[0], 4 * n, 3, BBGPU_COSET_FFT));
+        RC(commit_end(P, out));
         memcpy(proof.Z_1, out[0], 64);
         challenges.alpha = challenge(transcript_upto(1)); // compute_alpha, challenge.hpp:87-98
         return BBGPU_OK;
@@ -397,12 +438,7 @@ class PlonkProver {
     int compute_quotient_numerators()
     {
         const size_t n4 = 4 * n, n2 = 2 * n;
-        for (int k = 0; k < 3; k++) RC(poly::copy_pad(w_fft[k], w[k], n, n4, st)); // prover.cpp:418-425
-        RC(ntt_batch(w_fft[0], n4, 3, BBGPU_COSET_FFT));
-        RC(copy(sigma[0], sigma_lagrange[0], 3 * n)); // :245-247, :253-276
-        RC(ntt_batch(sigma[0], n, 3, BBGPU_IFFT_WITH_CONSTANT, &challenges.beta));
-        for (int k = 0; k < 3; k++) RC(poly::sigma_prepare(s_fft[k], sigma[k], w[k], n, n4, challenges.gamma, st));
-        RC(ntt_batch(s_fft[0], n4, 3, BBGPU_COSET_FFT));
+        // w_fft (the wires on the 4n coset) and s_fft (w_i + beta sigma_i + gamma there) were enqueued beside the wire / Z commitments
         RC(poly::copy_pad(z_fft, z, n, n4, st)); // :440
         RC(ntt(z_fft, n4, BBGPU_COSET_FFT_WITH_CONSTANT, &challenges.alpha)); // :278
         poly::QuotLargeArgs L{};
