@@ -165,12 +165,15 @@ struct ScanArgs {
     uint32_t reverse;     // MODE 0: 1 = suffix products
     uint32_t inclusive;   // output includes element i itself
     uint32_t has_carry;   // 0: top level, bcarry is not read
-    Limbs9 zpow[12];      // MODE 1: z^(RUN * 2^j), j < 8, for the thread-level doubling (2^261 form); [8] = z, [9] = z^RUN
+    uint32_t fused_nb;    // phase 3, <= SCAN_T blocks: every workgroup scans the bpart[0..fused_nb) block totals itself instead of reading bcarry
+    uint32_t* total_out;  // fused: where block 0 leaves the combination of everything
+    Limbs9 zpow[20];      // MODE 1: z^(RUN * 2^j), j < 8, for the thread-level doubling (2^261 form); [8] = z, [9] = z^RUN;
+                          // [12 + j] = z^(SCAN_BLOCK * 2^j), j < 8: the doubling over whole blocks of the fused phase 3
 };
 
 // LDS doubling scan over the SCAN_T thread partials of a block.  v = this thread's inclusive partial on entry; returns the
 // exclusive partial (combination of all LATER threads for suffix scans / EARLIER threads for prefix scans).
-template <int MODE> __device__ __forceinline__ FrM block_scan(FrM v, uint32_t* sh, bool towards_high, const ScanArgs& A, FrM* total)
+template <int MODE, int ZB = 0> __device__ __forceinline__ FrM block_scan(FrM v, uint32_t* sh, bool towards_high, const ScanArgs& A, FrM* total)
 {
     // position p runs in scan order: p = 0 is the first element combined
     const uint32_t t = threadIdx.x;
@@ -192,7 +195,7 @@ template <int MODE> __device__ __forceinline__ FrM block_scan(FrM v, uint32_t* s
                 // suffix Horner: scan order runs from the highest index down; position p holds S over `off` earlier
                 // positions: S_new = S_here + z^(RUN * off) * S_earlier ... earlier positions are HIGHER indices, so
                 // S(i..) = S_here + z^(len_here) * S_later with len_here = RUN * off thread-runs combined so far
-                v = tight2<Fr>(add(v, mul(o, cst(A.zpow[j]))));
+                v = tight2<Fr>(add(v, mul(o, cst(A.zpow[ZB + j]))));
             }
         }
         __syncthreads();
@@ -266,15 +269,40 @@ template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase1(Scan
 // phase 3: out_i from the block carry, the thread partial and the in-run elements
 template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase3(ScanArgs A0, ScanArgs A1)
 {
+    __shared__ uint32_t sh[NL * SCAN_T];
     const ScanArgs& A = blockIdx.y ? A1 : A0;
     const uint32_t t = threadIdx.x, b = blockIdx.x;
-    const uint32_t base = b * SCAN_BLOCK + t * RUN;
-    if (base >= A.n) return;
-    const uint32_t tid = b * SCAN_T + t;
+    if (b * SCAN_BLOCK >= A.n) return; // whole workgroup: the two scans may differ in length
     const bool suffix = (MODE == 1) || A.reverse;
+    // <= SCAN_T blocks: the exclusive scan of the block totals (phase 1 + phase 3 of the nested level: two launches of one workgroup
+    // each, ~40 us of a 2^16-element scan's ~95) is done here by every workgroup for itself, lane t standing for block t
+    FrM carry = mul(fe_zero<Fr>(), fe_from<Fr>(Fr::ONE));
+    if (A.fused_nb) {
+        FrM v;
+        if (MODE == 0) {
+            v = mul(ld_or_id<0>(A.bpart, t, A.fused_nb), fe_from<Fr>(Fr::ONE));
+        } else {
+            FrH h = ld_or_id<1>(A.bpart, t, A.fused_nb);
+            v = tight2<Fr>(h);
+        }
+        FrM total;
+        const FrM ex = block_scan<MODE, 12>(v, sh, !suffix, A, &total);
+        if (t == b) {
+#pragma unroll
+            for (int k = 0; k < NL; k++) sh[k] = ex.d[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NL; k++) carry.d[k] = sh[k];
+        if (b == 0 && t == 0 && A.total_out) stv(A.total_out, 0, total);
+    }
+    const uint32_t base = b * SCAN_BLOCK + t * RUN;
+    if (base >= A.n || !A.out) return; // (a scan wanted for its total only has no output vector)
+    const uint32_t tid = b * SCAN_T + t;
     if (MODE == 0) {
         FrM acc = mul(ldv(A.tpart, tid), fe_from<Fr>(Fr::ONE)); // everything before (after) this run
-        if (A.has_carry) acc = mulv(ldv(A.bcarry, b), ldv(A.tpart, tid));
+        if (A.fused_nb) acc = mulv(carry, ldv(A.tpart, tid));
+        else if (A.has_carry) acc = mulv(ldv(A.bcarry, b), ldv(A.tpart, tid));
         if (!suffix) {
             for (uint32_t k = 0; k < RUN && base + k < A.n; k++) {
                 const FrV x = ldv(A.in, base + k);
@@ -306,7 +334,8 @@ template <int MODE> __global__ void __launch_bounds__(SCAN_T) k_scan_phase3(Scan
         for (int j = 0; j < 8; j++)
             if ((after >> j) & 1) zp = mul(zp, cst(A.zpow[j]));
         FrH acc = ldv(A.tpart, tid);
-        if (A.has_carry) acc = add(mul(ldv(A.bcarry, b), zp), ldv(A.tpart, tid));
+        if (A.fused_nb) acc = add(mul(carry, zp), ldv(A.tpart, tid));
+        else if (A.has_carry) acc = add(mul(ldv(A.bcarry, b), zp), ldv(A.tpart, tid));
         const FrC z = cst(A.zpow[8]);
         for (int k = RUN - 1; k >= 0; k--) {
             if (base + k >= A.n) continue; // padded zeros do not change acc
@@ -789,6 +818,8 @@ static void scan_fill(int mode, const ScanJob& J, uint8_t* base, ScanArgs& A, Sc
         A.zpow[9] = host::limbs_m261(zr);
         // nested level: its "elements" are whole blocks, so its z is z^SCAN_BLOCK
         host::Fr zb = host::fr_pow(J.z, SCAN_BLOCK);
+        p = zb;
+        for (int j = 0; j < 8; j++) { A.zpow[12 + j] = host::limbs_m261(p); p = host::fr_sqr(p); }
         host::Fr zbr = host::fr_pow(zb, RUN);
         p = zbr;
         for (int j = 0; j < 8; j++) { B.zpow[j] = host::limbs_m261(p); p = host::fr_sqr(p); }
@@ -823,6 +854,22 @@ int scan_pair(int mode, const ScanJob* jobs, int count, Scratch& S, hipStream_t 
     for (int j = 0; j < count; j++)
         if (!jobs[j].out) A3[j].n = 0;
     const dim3 g1((uint32_t)nbmax, count), gb(1, count);
+    static const bool fuse_env = [] { const char* e = getenv("BBGPU_SCAN_FUSED"); return !e || atoi(e) != 0; }(); // tuning knob
+    const bool fused = fuse_env && nbmax <= (size_t)SCAN_T;
+    if (fused) {
+        for (int j = 0; j < count; j++) {
+            A3[j].fused_nb = (uint32_t)((jobs[j].n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+            A3[j].total_out = B[j].bpart;
+            A3[j].n = A[j].n; // also the scans without an output vector run phase 3 (for the total)
+        }
+        if (mode == 0) {
+            k_scan_phase1<0><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
+            k_scan_phase3<0><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
+        } else {
+            k_scan_phase1<1><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
+            k_scan_phase3<1><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
+        }
+    } else
     if (mode == 0) {
         k_scan_phase1<0><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
         k_scan_phase1<0><<<gb, SCAN_T, 0, st>>>(B[0], B[1]);
@@ -859,13 +906,20 @@ int horner_suffix(const uint64_t* d_in, uint64_t* d_out, size_t n, const host::F
 }
 
 // polynomial_arithmetic::evaluate (:337-373): result left in a 32-byte device slot (canonical); evaluate() also fetches it
+// workgroups of an evaluation: every lane pays ~log2(lanes) multiplications for its z^t on top of one per coefficient, so a lane takes
+// 8 coefficients (Horner in z^T) before the grid grows: at n = 2^16 one lane per coefficient cost 17 dependent multiplications each
+// (the prover's seven openings: 73 us), 8 per lane cost 8 + 13 for eight (21 us)
+static uint32_t eval_blocks(size_t n)
+{
+    return (uint32_t)std::min<size_t>(std::max<size_t>((n + (size_t)PT * 8 - 1) / ((size_t)PT * 8), 1), 256);
+}
 int evaluate_to_device(const uint64_t* d_coeffs, size_t n, const host::Fr& z, uint64_t* d_result, Scratch& S, hipStream_t st)
 {
     if (n == 0) {
         HIPCHK(hipMemsetAsync(d_result, 0, 32, st));
         return BBGPU_OK;
     }
-    const uint32_t blocks = (uint32_t)std::min<size_t>((n + PT - 1) / PT, 256);
+    const uint32_t blocks = eval_blocks(n);
     int rc = S.ensure((size_t)blocks * 32 + 64);
     if (rc) return rc;
     const uint32_t nt = blocks * PT;
@@ -904,7 +958,7 @@ int evaluate_batch_to_device(const EvalJob* jobs, int count, const host::Fr z[2]
     uint32_t maxb = 1;
     for (int j = 0; j < count; j++) {
         const size_t n = jobs[j].n;
-        const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>((n + PT - 1) / PT, 1), 256);
+        const uint32_t blocks = eval_blocks(n);
         A.c[j] = (const uint32_t*)jobs[j].coeffs;
         A.n[j] = (uint32_t)n;
         A.blocks[j] = blocks;
