@@ -1265,9 +1265,25 @@ static uint32_t chunk_len(size_t n, uint32_t nw)
     }
     static const int forced = [] { const char* e = getenv("BBGPU_CHUNK"); return e ? std::max((int)MIN_CHUNK, atoi(e)) : 0; }(); // tuning knob (small MSMs)
     if (forced) return (uint32_t)std::max<uint64_t>(forced, (m + ((uint64_t)1 << 24) - 1) >> 24);
-    const uint64_t cap = (uint64_t)acc_capacity_lanes() * (uint64_t)waves;
-    uint32_t ch = (uint32_t)((m + cap - 1) / cap);
-    return ch < MIN_CHUNK ? MIN_CHUNK : ch;
+    if (waves > 1) {
+        const uint64_t cap = (uint64_t)acc_capacity_lanes() * (uint64_t)waves;
+        return std::max<uint32_t>(MIN_CHUNK, (uint32_t)((m + cap - 1) / cap));
+    }
+    // k = 1 .. 3 workgroups per CU, every lane `ch` entries: the kernel lasts ~ch * step(k), step(k) = time of one mixed addition of a wave
+    // with k waves on its SIMD: ~6.4 us alone (dependent multiplications), k * 4.46 us once two waves saturate the multiplier
+    // (14.7e9 mixed additions per second chip-wide).  A grid that is NOT a whole number of workgroups per CU runs at the pace of the
+    // fullest CU: 2^16 points x 17 windows at ch = 8 is 543 workgroups = 2.1 per CU, paced by the CUs holding 3 (107 us);
+    // ch = 9 gives 484 = at most 2 per CU (80 us).
+    static const double step[3] = { 6.4, 9.2, 13.4 }; // two waves reach ~97 % of the multiplier rate, three all of it
+    const uint64_t per_k = (uint64_t)acc_capacity_lanes() / acc_wg_per_cu(); // lanes of one workgroup per CU
+    uint32_t best = 0;
+    double best_cost = 0.0;
+    for (uint32_t k = 1; k <= acc_wg_per_cu() && k <= 3; k++) {
+        const uint32_t ch = std::max<uint32_t>(MIN_CHUNK, (uint32_t)((m + per_k * k - 1) / (per_k * k)));
+        const double cost = ch * step[k - 1];
+        if (!best || cost < best_cost) { best = ch; best_cost = cost; }
+    }
+    return best;
 }
 static size_t arena_points(const MsmPlan& P, uint32_t nw)
 {
