@@ -1112,14 +1112,31 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
             if (j == 0 && l == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
             return;
         }
-        bool first = true;
-        for (uint32_t k = t0 + j; k <= t1; k += Q) { // quad-uniform trip count
+        // the next partial is loaded before the addition of the current one starts (a quad's partials are Q slots apart)
+        uint32_t k = t0 + j;
+        if (k <= t1) {
             const uint32_t* src = partials + (size_t)(b + k) * RAW_WORDS + NL * l;
-            FqN q;
 #pragma unroll
-            for (int i = 0; i < NL; i++) q.d[i] = src[i];
-            acc = first ? q : quad_add(acc, q, l);
-            first = false;
+            for (int i = 0; i < NL; i++) acc.d[i] = src[i];
+            FqN q = quad_zero();
+            k += Q;
+            if (k <= t1) {
+                src = partials + (size_t)(b + k) * RAW_WORDS + NL * l;
+#pragma unroll
+                for (int i = 0; i < NL; i++) q.d[i] = src[i];
+            }
+            while (k <= t1) { // quad-uniform trip count
+                FqN qn = quad_zero();
+                const uint32_t kn = k + Q;
+                if (kn <= t1) {
+                    src = partials + (size_t)(b + kn) * RAW_WORDS + NL * l;
+#pragma unroll
+                    for (int i = 0; i < NL; i++) qn.d[i] = src[i];
+                }
+                acc = quad_add(acc, q, l);
+                q = qn;
+                k = kn;
+            }
         }
     }
     for (uint32_t off = Q >> 1; off >= 1; off >>= 1) {
@@ -1229,6 +1246,15 @@ static uint32_t acc_wg_per_cu()
     if (!v) {
         v = 3;
         if (const char* e = getenv("BBGPU_ACC_WGS")) v = std::min(4, std::max(1, atoi(e))); // tuning knob (4 = no reservation)
+    }
+    return (uint32_t)v;
+}
+static uint32_t acc_lds_reserve()
+{
+    static int v = -1;
+    if (v < 0) {
+        v = acc_wg_per_cu() == 3 ? (int)ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0);
+        if (const char* e = getenv("BBGPU_ACC_LDS")) v = std::min(64 * 1024, std::max(0, atoi(e))); // tuning knob
     }
     return (uint32_t)v;
 }
@@ -1542,7 +1568,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     // next accumulation's start (measured in round 1: +1..3 % per step).
     static const int fold_env = [] { const char* e = getenv("BBGPU_FOLD_TAIL"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force
     const bool fold = fold_env >= 0 ? fold_env != 0 : ((uint64_t)n * nw <= ((uint64_t)1 << 22));
-    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_wg_per_cu() == 3 ? ACC_LDS_RESERVE : (acc_wg_per_cu() == 2 ? 60 * 1024 : 0), st>>>(points, sorted, gstart, partials, total_buckets, ch, acc_prio(), fold ? heavy : nullptr);
+    msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_lds_reserve(), st>>>(points, sorted, gstart, partials, total_buckets, ch, acc_prio(), fold ? heavy : nullptr);
     if (tm_acc) {
         HIPCHK(hipEventRecord(ev[3], st));
         if (int rc = acc_ring_record(S, st)) return rc;
@@ -1551,17 +1577,19 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     }
     if (!fold) HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
     static const bool quad_tail = [] { const char* e = getenv("BBGPU_QUAD_TAIL"); return !e || atoi(e) != 0; }(); // 0: one point per lane (round 1)
+    static const uint64_t quad_merge_max_entries = [] { const char* e = getenv("BBGPU_QUAD_MERGE_MAX_LOG"); return (uint64_t)1 << (e ? std::min(30, std::max(10, atoi(e))) : 21); }(); // tuning knob
     static const int quad_merge = [] { const char* e = getenv("BBGPU_QUAD_MERGE"); return e ? atoi(e) : 1; }(); // tuning knob: 0 off, 1 on, 2.. = 1 + forced logQ
-    // The merge of a full-size MSM keeps every SIMD busy with one point per lane (2^20: 196,608 additions, 42 us either way; a quad addition is
-    // 4 x 1,250 lane-instructions against 3,700); quads pay where the lanes do not fill the chip: a 2-of-17-window share of a 2^16-point MSM
-    // 0.200 -> 0.183 ms latency, 0.102 -> 0.094 ms per step (tools/msm_ab.py, one box).
-    if (quad_tail && (quad_merge > 1 || (quad_merge == 1 && (uint64_t)n * nw <= ((uint64_t)1 << 19)))) {
+    // A quad addition is 4 x 1,350 lane-instructions against 3,700 for one point per lane: quads shorten the chain where the lanes do not
+    // fill the chip, and cost issue slots where they do.  2^20 points: 196,608 additions, ~42 us either way (one wave per SIMD and three
+    // dependent 9-us additions, or four waves per SIMD sharing the multiplier) -- the plain kernel stays.  2^16 points x 17 windows
+    // (8 partials per bucket): 2 quads per bucket 0.261 -> 0.253 ms latency; a 2-of-17-window share 0.200 -> 0.187 ms (tools/msm_ab.py).
+    if (quad_tail && (quad_merge > 1 || (quad_merge == 1 && (uint64_t)n * nw <= quad_merge_max_entries))) {
         // quads per bucket: about half the expected number of partials, within one resident wave of tail workgroups (~2^18 lanes)
         uint32_t logQ = 0;
-        while ((2u << logQ) < avg_partials && logQ < 4 && ((uint64_t)total_buckets << (logQ + 3)) <= ((uint64_t)1 << 18)) logQ++;
+        while ((2u << logQ) < avg_partials && logQ < 4 && ((uint64_t)total_buckets << (logQ + 3)) <= ((uint64_t)1 << 17)) logQ++;
         if (quad_merge > 1) logQ = std::min(4, quad_merge - 2);
         msm_merge_quad_kernel<<<(uint32_t)((((uint64_t)total_buckets << (logQ + 2)) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch,
-                                                                                                                                  std::max(6u, 8u << logQ), logQ);
+                                                                                                                                  std::max(32u, 8u << logQ), logQ);
     } else
     msm_merge_kernel<<<(uint32_t)((((uint64_t)total_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
                                                                                                                      total_buckets, ch, merge_light, logG);

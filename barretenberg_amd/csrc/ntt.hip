@@ -337,7 +337,10 @@ template <int FLAGS> __device__ __forceinline__ void ntt_finish_store(const NttP
     store8(A.out + (size_t)blockIdx.y * A.out_bstride + 8 * gidx, w);
 }
 
-template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) ntt_pass_fused_kernel(NttPassArgs A)
+#ifndef NTT_OCC_ATTR
+#define NTT_OCC_ATTR // A/B knob: e.g. -DNTT_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(5,5)))'
+#endif
+template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT_OCC_ATTR ntt_pass_fused_kernel(NttPassArgs A)
 {
     extern __shared__ uint32_t lds[]; // [9][cols * S]
     const uint32_t S = 1u << A.log_s, cols = A.cols, E = cols * S, quarter = S >> 2, ngr = cols * quarter;
