@@ -309,6 +309,44 @@ def test_msm_skewed_scalars(gpu, oracle, msm_small):
         assert (int(got[7]) >> 63) == (int(want[7]) >> 63), name
 
 
+def test_msm_fuzz_sizes_and_distributions(gpu, oracle, msm_small):
+    """48 seeded cases against the oracle: sizes with every residue mod 8 on both sides of the window-table threshold (n % 8 == 0 takes the
+    16-byte digit loads and the LDS-staged sort passes, the rest the one-digit-per-load kernels; below 1024 points one bucket set per
+    window), scalar mixtures from uniform to degenerate (zeros, +-1, one repeated value, 20-bit values, a single non-zero scalar)"""
+    g, srs, table, scalars = msm_small
+    one = oracle.const(FR, "one")
+    minus_one = oracle.neg(FR, one)
+    zero = np.zeros(4, dtype=np.uint64)
+    rng = np.random.default_rng(20260402)
+    sizes = [25, 26, 63, 64, 200, 1000, 1023, 1024, 1025, 1032, 2047, 2048, 2056, 3001, 4096, 5000]
+    for case in range(48):
+        n = sizes[case % len(sizes)] + (int(rng.integers(0, 8)) if case >= 32 else 0)
+        kind = case % 6
+        sc = scalars[case * 5: case * 5 + n].copy()
+        if kind == 1:    # a third zeros, a third +-1
+            pick = rng.integers(0, 4, n)
+            sc[pick == 0] = zero
+            sc[pick == 1] = one
+            sc[pick == 2] = minus_one
+        elif kind == 2:  # one value everywhere
+            sc[:] = scalars[case]
+        elif kind == 3:  # 20-bit values
+            sc = np.stack([oracle.to_mont(FR, np.array([int(v), 0, 0, 0], dtype=np.uint64)) for v in rng.integers(0, 1 << 20, n)])
+        elif kind == 4:  # a single non-zero scalar
+            keep = int(rng.integers(0, n))
+            v = sc[keep].copy()
+            sc[:] = zero
+            sc[keep] = v
+        elif kind == 5:  # runs of repeated values (what selector-like witnesses look like)
+            sc = np.repeat(scalars[case: case + (n + 15) // 16], 16, axis=0)[:n].copy()
+        sc = aligned_copy(sc)
+        want = oracle.msm_affine(sc, table, n)
+        got = gpu.pippenger(sc, table, n)
+        assert (int(got[7]) >> 63) == (int(want[7]) >> 63), (case, n, kind)
+        if not (int(want[7]) >> 63):
+            assert np.array_equal(got[:8], want[:8]), (case, n, kind)
+
+
 def test_msm_additivity_large(gpu, oracle):
     """sizes beyond the golden fixtures (non-power-of-two, and 2^21 which exceeds the window-table limit):
     MSM(n) == MSM(first half) + MSM(second half), through independent code paths (different n => different chunking)"""
