@@ -1562,12 +1562,12 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     while ((1u << logG) < avg_partials && logG < 6 && ((uint64_t)G * P.nb << (logG + 1)) <= ((uint64_t)1 << lanes_log)) logG++;
     const uint32_t merge_light = std::max(6u, 8u << logG);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
-    // Small MSMs (the prover's 2^16-point commitments, a rank's share of an 8-way split) are chains of dependent launches: their three
-    // helper launches -- two fills and the device-to-host copy -- are folded into the kernels around them, the last kernel writing the 8 KiB
-    // of results straight into the pinned host buffer.  Not for the full-size pipelined step: there the earlier tail collides with the
-    // next accumulation's start (measured in round 1: +1..3 % per step).
-    static const int fold_env = [] { const char* e = getenv("BBGPU_FOLD_TAIL"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force
-    const bool fold = fold_env >= 0 ? fold_env != 0 : ((uint64_t)n * nw <= ((uint64_t)1 << 22));
+    // An MSM is a chain of dependent launches: its three helper launches -- two fills and the device-to-host copy, ~5 us each -- are folded
+    // into the kernels around them, the last kernel writing the 8 KiB of results straight into the pinned host buffer.  (Round 1 measured the
+    // folded tail 1..3 % SLOWER per pipelined 2^20 step and kept it for small MSMs only; with the round-2 tail it is level or ahead at every
+    // size -- 1.371 vs 1.385 ms latency, 1.174 vs 1.176 ms per step, tools/msm_ab.py, two alternating runs in one box -- and is the one path.)
+    static const int fold_env = [] { const char* e = getenv("BBGPU_FOLD_TAIL"); return e ? atoi(e) : 1; }(); // tuning knob: 0 = separate fills and copy
+    const bool fold = fold_env != 0;
     msm_accumulate_kernel<<<(max_chunks + MSM_THREADS - 1) / MSM_THREADS, MSM_THREADS, acc_lds_reserve(), st>>>(points, sorted, gstart, partials, total_buckets, ch, acc_prio(), fold ? heavy : nullptr);
     if (tm_acc) {
         HIPCHK(hipEventRecord(ev[3], st));
