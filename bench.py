@@ -215,7 +215,7 @@ def device_ntt_leg(G, dev, d_vec, n, kinds, steps, warmup, barrier):
 def ntt_roofline(n, device_ms, traffic):
     b = 2 * 32 * n  # the vector read once, written once
     return {"bound": "hbm", "achieved": b / (device_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "ntt_pass_kernel x2", "algorithmic_bytes": b}
+            "traffic": traffic, "kernel": "ntt_pass_fused_kernel x2", "algorithmic_bytes": b}
 
 
 def main():

@@ -17,8 +17,14 @@ echo "== calibration FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv
 echo "== calibration WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $ROOT/tools/ubench/ubench_traffic > $OUT/cal_write.log 2>&1 || exit 1
 echo "== SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary > $OUT/sq.log 2>&1 || exit 1
 echo "== prover trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/plonk -- python3 $ROOT/tools/plonk_bench.py --reps 10 --no-reference > $OUT/plonk.log 2>&1 || exit 1
+echo "== latency traces"
+for L in 20 16; do rocprofv3 --kernel-trace --output-format csv -d $OUT/lat$L -- python3 $ROOT/tools/latency_run.py $L > $OUT/lat$L.log 2>&1 || exit 1; done
 cd $ROOT
 echo "== summaries"
+python tools/timeline.py $OUT/trace 2 > $OUT/timeline_steady_state.txt
+python tools/window_timeline.py $OUT/plonk 0.7 2700 > $OUT/prover_timeline.txt
+for L in 20 16; do echo "== one 2^$L-point MSM at a time (tools/latency_run.py): start, duration, gap (us), kernel"; python tools/latency_timeline.py $OUT/lat$L; done > $OUT/latency_timeline.txt
+rm -rf $OUT/lat20 $OUT/lat16
 python tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/${TAG}_pmc_traffic.json
 python tools/pmc_sq_summary.py $OUT/sq $OUT/${TAG}_pmc_sq.json
 python tools/acc_spacing.py $OUT/trace | tee $OUT/acc_spacing.txt
@@ -33,6 +39,8 @@ python tools/shard_sim.py $OUT/${TAG}_shard_prediction.json > $OUT/shard_sim.txt
 python tools/ntt_sizes.py > $OUT/ntt_sizes.txt 2>&1
 python tools/msm_ab.py > $OUT/msm_ab.txt 2>&1
 python tools/small_sizes.py > $OUT/small_sizes.txt 2>&1
+python tools/exchange_cost.py > $OUT/exchange_cost.txt 2>&1
+python tools/host_finish_cost.py > $OUT/host_finish_cost.txt 2>&1
 echo "== plain bench line"
 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 tail -c 400 $OUT/${TAG}_bench_line.json

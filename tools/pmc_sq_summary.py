@@ -23,6 +23,6 @@ for k, v in sorted(agg.items()):
               "valu_share_of_issued": round(m["SQ_ACTIVE_INST_VALU"] / max(m["SQ_ACTIVE_INST_ANY"], 1.0), 3)}
 json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
                       "--output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-plonk", "kernels": res}, open(out, "w"), indent=1)
-for k in ("msm_accumulate_kernel", "ntt_pass_kernel<2>", "ntt_pass_kernel<16>", "sortB_kernel", "msm_rowcol_kernel"):
-    if k in res:
+for k in res:
+    if any(w in k for w in ("msm_accumulate", "ntt_pass", "sortB", "sortA_scatter", "msm_rowcol", "msm_merge_kernel", "msm_digits")):
         print(k, res[k]["wave_time_fraction"], "VALU wave-instructions/launch %.3g" % res[k]["mean_per_launch"].get("SQ_INSTS_VALU", 0))
