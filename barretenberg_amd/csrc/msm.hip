@@ -10,14 +10,16 @@
 //   * scalars: from-Montgomery and signed base-2^c digits in one pass (K0).  No GLV split: with the bucket work
 //     spread over W * 2^(c-1) independent accumulators the endomorphism buys nothing on a GPU, and reading only the
 //     even (base) entries of the caller's endo table halves point traffic.
-//   * binning instead of scatter-add: per window a counting sort of point indices by bucket, histograms and cursors
-//     private to a workgroup in LDS (128 KiB of the CU's 160 KiB at c = 16), no global atomics (K1-K3).
+//   * binning instead of scatter-add: a two-pass counting sort of (window, point) pairs by bucket, histograms and cursors
+//     private to a workgroup in LDS, eight digits per 16-byte load, both scatters staged through LDS so that the writes
+//     leave as coalesced runs; no global atomics (K1-K3).
 //   * accumulation (K4, ~90% of the time): one lane per (window, bucket), XYZZ accumulator in VGPRs, points gathered
 //     from the resident SRS in the kernels' Montgomery-261 form; 524,288 independent chains at n = 2^20 keep every
 //     SIMD issuing v_mad_u64_u32.  Integer-VALU bound: 2^20 * 16 madds * 10 field multiplies.
-//   * bucket reduction (K5): sum_b (b+1) B_b per window without a serial running sum: row sums and column sums of the
-//     bucket matrix by log-depth folds, then bit-sliced sums; the O(c) leftover points per window are combined by the
-//     host with ~256 doublings (host_g1.hpp) and normalised once.
+//   * bucket reduction (K5): sum_b (b+1) B_b per bucket set without a serial running sum: row sums and column sums of the
+//     bucket matrix by log-depth trees, then bit-sliced sums, every point spread over the four lanes of a quad
+//     (g1_quad.hpp: four multiplication steps per addition instead of fourteen); the O(c) leftover points per bucket set
+//     are combined by the host (host_g1.hpp) and normalised once.
 //   * multi-GPU: windows are independent, so rank g takes a window range and returns a normalised partial sum.
 #include <hip/hip_runtime.h>
 
@@ -47,7 +49,7 @@ using Fr = FrP;
 #define FRONT_PRIO() __builtin_amdgcn_s_setprio(BBGPU_FRONT_PRIO)
 constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
 constexpr int MSM_MAX_C = 16;    // largest window without tables (one bucket set per window); digits stored as int16
-constexpr int MSM_MAX_TABLE_C = 17; // with tables (one shared bucket set): 17-bit windows -> 15 of them, digits stored as uint16 magnitude + sign bit
+// (with tables, one shared bucket set: up to 17-bit windows -> 15 of them at 2^20, digits stored as uint16 magnitude + sign bit; capi.hip picks the width)
 constexpr int MSM_THREADS = 256;
 constexpr int MSM_MAX_JOBS = 4;  // MSMs over the same points issued as one batch (one bucket set each)
 
