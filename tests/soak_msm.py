@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Soak run (not collected by pytest; `python tests/soak_msm.py [seconds]` on the GPU box): random sizes and scalar mixtures against the oracle for a
+fixed wall-clock budget, plus pipelined batches whose results must equal the one-at-a-time results.  Looks for what a single pass of the parity
+suite cannot: launch-to-launch nondeterminism (a missing barrier in the LDS-staged sort passes, a race between the MSM slots)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from barretenberg_amd import BbGpu
+from oracle.pyoracle import FR, Oracle, aligned_copy, build
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+build()
+O = Oracle()
+G = BbGpu(0)
+G.set_host_thresholds(0, 0)
+rng = np.random.default_rng(int(time.time()))
+N = 1 << 15
+x = O.random_scalars(11, 1)[0]
+srs = O.make_srs(x, N)
+table = O.point_table(srs)
+pool = O.random_scalars(12, N)
+one = O.const(FR, "one"); minus_one = O.neg(FR, one); zero = np.zeros(4, dtype=np.uint64)
+t_end = time.time() + budget
+cases = bad = 0
+while time.time() < t_end:
+    n = int(rng.integers(25, 20000))
+    if rng.integers(0, 3) == 0:
+        n &= ~7
+        n = max(n, 32)
+    sc = pool[rng.permutation(N)[:n]].copy()
+    kind = int(rng.integers(0, 5))
+    if kind == 1:
+        pick = rng.integers(0, 4, n); sc[pick == 0] = zero; sc[pick == 1] = one; sc[pick == 2] = minus_one
+    elif kind == 2:
+        sc[:] = pool[int(rng.integers(0, N))]
+    elif kind == 3:
+        sc = np.repeat(pool[: (n + 31) // 32], 32, axis=0)[:n].copy()
+    sc = aligned_copy(sc)
+    want = O.msm_affine(sc, table, n)
+    got = G.pippenger(sc, table, n)
+    cases += 1
+    ok = (int(got[7]) >> 63) == (int(want[7]) >> 63) and ((int(want[7]) >> 63) or np.array_equal(got[:8], want[:8]))
+    if not ok:
+        bad += 1
+        print("MISMATCH n=%d kind=%d" % (n, kind), flush=True)
+print("oracle comparisons: %d cases, %d mismatches" % (cases, bad), flush=True)
+
+# pipelined: 4 different scalar vectors, two and three in flight, against their one-at-a-time results, at 2^15 and 2^20
+for lg in (15, 20):
+    n = 1 << lg
+    xs = np.random.default_rng(3).integers(0, 1 << 64, size=4, dtype=np.uint64); xs[3] &= np.uint64(0x1FFFFFFFFFFFFFFF)
+    h = G.srs_generate(xs, n)
+    ds = []
+    for j in range(4):
+        s = np.random.default_rng(100 + j).integers(0, 1 << 64, size=(n, 4), dtype=np.uint64); s[:, 3] &= np.uint64(0x1FFFFFFFFFFFFFFF)
+        ds.append(torch.from_numpy(s.view(np.int64)).cuda())
+    ref = [G.msm_wait(G.msm_device_async(h, d.data_ptr(), n)) for d in ds]
+    rounds = mism = 0
+    t1 = time.time() + budget / 4
+    while time.time() < t1:
+        for depth in (2, 3):
+            infl, out = [], []
+            for k in range(12):
+                infl.append((k % 4, G.msm_device_async(h, ds[k % 4].data_ptr(), n)))
+                if len(infl) == depth:
+                    j, t = infl.pop(0); out.append((j, G.msm_wait(t)))
+            while infl:
+                j, t = infl.pop(0); out.append((j, G.msm_wait(t)))
+            rounds += 1
+            for j, r in out:
+                if not np.array_equal(r, ref[j]):
+                    mism += 1
+    print("pipelined 2^%d: %d rounds of 12 MSMs, %d results differing from the one-at-a-time result" % (lg, rounds, mism), flush=True)
+    bad += mism
+sys.exit(1 if bad else 0)
