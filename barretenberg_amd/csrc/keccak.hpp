@@ -5,6 +5,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace bbgpu {
@@ -51,7 +52,7 @@ static inline void keccak256(const uint8_t* data, size_t len, uint64_t out[4])
         len -= rate;
     }
     memset(block, 0, rate);
-    memcpy(block, data, len);
+    if (len) memcpy(block, data, len);
     block[len] ^= 0x01;
     block[rate - 1] ^= 0x80;
     for (size_t i = 0; i < rate / 8; i++) {
@@ -66,10 +67,12 @@ static inline void keccak256(const uint8_t* data, size_t len, uint64_t out[4])
 // keccak.c:112-134: `count` field elements of 4 limbs, every limb written most-significant byte first
 static inline void hash_field_elements(const uint64_t* limbs, size_t count, uint64_t out[4])
 {
-    uint8_t buf[32 * 32];
+    uint8_t stack_buf[32 * 32]; // the prover's transcripts hold at most 22 elements
+    uint8_t* buf = count <= 32 ? stack_buf : (uint8_t*)malloc(count * 32);
     for (size_t i = 0; i < count * 4; i++)
         for (int b = 0; b < 8; b++) buf[8 * i + b] = (uint8_t)(limbs[i] >> (56 - 8 * b));
     keccak256(buf, count * 32, out);
+    if (buf != stack_buf) free(buf);
 }
 
 } // namespace host

@@ -1,0 +1,111 @@
+// The host-side PRODUCT code of the library (csrc/host_small.hpp, host_g1.hpp, host_g2.hpp, host_fr.hpp, keccak.hpp: the answers to tiny
+// sizes, the O(1) tail of an MSM, the transcript's G2 half, the Fiat-Shamir hash) compiled with -fsanitize=address,undefined and driven
+// against the oracle (oracle/bn254_oracle.c; test infrastructure).  Built and run by tests/test_host_small.py::test_host_code_under_sanitizers.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../barretenberg_amd/csrc/host_small.hpp"
+#include "../../barretenberg_amd/csrc/host_g2.hpp"
+#include "../../barretenberg_amd/csrc/keccak.hpp"
+#include "../../oracle/bn254_oracle.h"
+
+using namespace bbgpu::host;
+
+static int fails = 0;
+#define CHECK(c, ...) do { if (!(c)) { printf("FAIL %s:%d ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); fails++; } } while (0)
+
+int main()
+{
+    // ---- msm_small against the oracle's pippenger, n = 0 .. 40, scalars uniform, zero, one repeated value, non-canonical representatives
+    const size_t N = 40;
+    std::vector<uint64_t> srs(8 * N), table(16 * N), sc(4 * N);
+    uint64_t x[4];
+    orc_random_scalars(77, 1, x);
+    orc_make_srs(x, N, srs.data());
+    orc_generate_point_table(srs.data(), table.data(), N);
+    const uint64_t* r_mod = orc_const(1, "modulus");
+    for (int mode = 0; mode < 4; mode++) {
+        orc_random_scalars(100 + mode, N, sc.data());
+        if (mode == 1) memset(sc.data(), 0, 32 * N);
+        if (mode == 2) for (size_t i = 1; i < N; i++) memcpy(&sc[4 * i], &sc[0], 32);
+        if (mode == 3) { // [r, 2r): what the prover may hand over
+            for (size_t i = 0; i < N; i++) {
+                unsigned __int128 c = 0;
+                for (int l = 0; l < 4; l++) { c += (unsigned __int128)sc[4 * i + l] + r_mod[l]; sc[4 * i + l] = (uint64_t)c; c >>= 64; }
+            }
+        }
+        for (size_t n = 0; n <= N; n += (n < 8 ? 1 : 7)) {
+            uint64_t want[12], got[12];
+            orc_pippenger(sc.data(), table.data(), n, 0, want);
+            uint64_t wn[12];
+            orc_g1_normalize(want, wn);
+            Xyzz p = msm_small(sc.data(), table.data(), n);
+            g1_to_normalised(p, got);
+            const bool winf = orc_g1_is_infinity(wn) != 0, ginf = (got[7] >> 63) != 0;
+            CHECK(winf == ginf, "msm_small infinity mode %d n %zu", mode, n);
+            if (!winf && !ginf) CHECK(!memcmp(wn, got, 64), "msm_small mode %d n %zu", mode, n);
+        }
+    }
+    // ---- batch normalisation = one by one
+    {
+        Xyzz pts[8];
+        uint64_t one_by_one[8][12], batch[8 * 12];
+        for (int i = 0; i < 8; i++) pts[i] = i == 3 ? g1_infinity() : msm_small(sc.data() + 4 * i, table.data() + 16 * i, 2);
+        for (int i = 0; i < 8; i++) g1_to_normalised(pts[i], one_by_one[i]);
+        g1_batch_to_normalised(pts, 8, batch);
+        for (int i = 0; i < 8; i++) CHECK(!memcmp(one_by_one[i], batch + 12 * i, 96), "batch normalise %d", i);
+    }
+    // ---- ntt_small against the oracle, 2 .. 64 elements, all seven kinds, non-canonical inputs
+    {
+        uint64_t cst[4];
+        orc_random_scalars(5, 1, cst);
+        for (int lg = 1; lg <= 6; lg++) {
+            const size_t n = (size_t)1 << lg;
+            for (int kind = 0; kind < 7; kind++) {
+                std::vector<uint64_t> a(4 * n), b;
+                orc_random_scalars(200 + lg, n, a.data());
+                b = a;
+                CHECK(orc_ntt(a.data(), n, kind, cst) == 0, "oracle ntt");
+                ntt_small(b.data(), lg, kind, cst);
+                CHECK(!memcmp(a.data(), b.data(), 32 * n), "ntt_small lg %d kind %d", lg, kind);
+            }
+        }
+    }
+    // ---- G2: (k1 + k2) G2 computed directly and by two scalar multiplications of the generator followed by a mixed addition
+    {
+        Fr k1, k2;
+        orc_random_scalars(9, 1, k1.d);
+        orc_random_scalars(10, 1, k2.d);
+        const Fr k12 = fr_add(k1, k2);
+        G2Affine a, b, c;
+        CHECK(g2_scalar_mul_affine(G2_ONE, k1, &a) && g2_scalar_mul_affine(G2_ONE, k2, &b) && g2_scalar_mul_affine(G2_ONE, k12, &c), "g2 scalar mul");
+        G2Jac ja = { a.x, a.y, { FQ_ONE, { { 0, 0, 0, 0 } } } };
+        const G2Jac s = g2_madd(ja, b);
+        const Fq2 zi = fq2_inv(s.z), zi2 = fq2_sqr(zi);
+        const Fq2 sx = fq2_mul(s.x, zi2), sy = fq2_mul(s.y, fq2_mul(zi2, zi));
+        CHECK(!memcmp(&sx, &c.x, 64) && !memcmp(&sy, &c.y, 64), "g2 additivity");
+    }
+    // ---- Keccak-256 of the empty string and of "abc" (FIPS 202 predecessor, the Ethereum variant the reference uses)
+    {
+        uint64_t h[4];
+        keccak256(nullptr, 0, h);
+        const uint8_t want0[32] = { 0xc5, 0xd2, 0x46, 0x01, 0x86, 0xf7, 0x23, 0x3c, 0x92, 0x7e, 0x7d, 0xb2, 0xdc, 0xc7, 0x03, 0xc0,
+                                    0xe5, 0x00, 0xb6, 0x53, 0xca, 0x82, 0x27, 0x3b, 0x7b, 0xfa, 0xd8, 0x04, 0x5d, 0x85, 0xa4, 0x70 };
+        uint8_t got[32];
+        memcpy(got, h, 32);
+        bool same = !memcmp(got, want0, 32);
+        if (!same) { // the digest may be kept as four big-endian words: compare as a multiset of bytes in either order
+            uint8_t rev[32];
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) rev[8 * i + j] = got[8 * i + 7 - j];
+            same = !memcmp(rev, want0, 32);
+            if (!same) { for (int i = 0; i < 32; i++) rev[i] = got[31 - i]; same = !memcmp(rev, want0, 32); }
+        }
+        CHECK(same, "keccak256(\"\")");
+        const uint8_t abc[3] = { 'a', 'b', 'c' };
+        keccak256(abc, 3, h); // only exercised under the sanitizers (partial block path)
+    }
+    printf(fails ? "FAILED %d\n" : "ALL OK %d\n", fails);
+    return fails ? 1 : 0;
+}

@@ -124,3 +124,23 @@ def test_nothing_larger_runs_on_the_host(lib):
             lib.pippenger(np.zeros((4, 4), dtype=np.uint64), np.zeros((8, 8), dtype=np.uint64), 4)
     finally:
         lib.set_host_thresholds(32, 16)
+
+
+def test_host_code_under_sanitizers(oracle):
+    """the host-side product code (host_small / host_g1 / host_g2 / host_fr / keccak) built with AddressSanitizer + UBSan (CPU build: the pool
+    offers no GPU sanitizer) and driven against the oracle: msm_small at n = 0 .. 40 over four scalar mixtures incl. [r, 2r) representatives,
+    batch normalisation, ntt_small for all seven kinds at 2 .. 64 elements, G2 additivity, Keccak-256"""
+    import os
+    import subprocess
+    import tempfile
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tempfile.gettempdir(), "bbgpu_test_host_sanitize")
+    ob = os.path.join(ROOT, "oracle", "_build")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+           os.path.join(ROOT, "tests", "cpp", "test_host_sanitize.cpp"), "-L" + ob, "-loracle", "-Wl,-rpath," + ob]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and ("asan" in b.stderr or "ubsan" in b.stderr or "sanitize" in b.stderr):
+        pytest.skip("no sanitizer runtime in this image: " + b.stderr[-200:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
