@@ -161,9 +161,14 @@ def test_shim_host_members_match_oracle(oracle):
     subprocess.run(["make", "-C", os.path.join(ROOT, "barretenberg_amd", "shim")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     exe = "/tmp/bbgpu_test_shim_host"
     pkg = os.path.join(ROOT, "barretenberg_amd")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shim_host.cpp"), "-L" + pkg, "-lbbshim", "-lbbgpu",
-                    "-Wl,-rpath," + pkg], check=True)
-    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    # the shim's own translation unit is compiled INTO the test with AddressSanitizer + UBSan (CPU build); plain link against libbbshim.so if the image has no sanitizer runtime
+    san = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                          os.path.join(ROOT, "tests", "cpp", "test_shim_host.cpp"), os.path.join(pkg, "shim", "bb_shim.cpp"), "-L" + pkg, "-lbbgpu", "-Wl,-rpath," + pkg],
+                         capture_output=True, text=True)
+    if san.returncode != 0:
+        subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shim_host.cpp"), "-L" + pkg, "-lbbshim", "-lbbgpu",
+                        "-Wl,-rpath," + pkg], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0")).stdout
     vec, width = {}, {}
     for line in out.splitlines():
         t = line.split()
