@@ -10,6 +10,7 @@
 
 #include "bn254_params.h"
 #include "fe.hpp"
+#include "host_modinv.hpp"
 
 namespace bbgpu {
 namespace host {
@@ -113,7 +114,7 @@ static inline Fr fr_pow(const Fr& a, uint64_t e)
     }
     return acc;
 }
-static inline Fr fr_inv(const Fr& a) // a^(r-2); inv(0) = 0
+static inline Fr fr_inv_fermat(const Fr& a) // a^(r-2); inv(0) = 0 -- the reference's route (field.hpp:258-348), kept as the check of fr_inv
 {
     const uint64_t e[4] = { FrHostP::P[0] - 2, FrHostP::P[1], FrHostP::P[2], FrHostP::P[3] };
     Fr acc = fr_one();
@@ -122,6 +123,15 @@ static inline Fr fr_inv(const Fr& a) // a^(r-2); inv(0) = 0
         if ((e[i >> 6] >> (i & 63)) & 1) acc = fr_mul(acc, a);
     }
     return acc;
+}
+// Montgomery in, Montgomery out, inv(0) = 0: (x R)^-1 = x^-1 R^-1 by divsteps (host_modinv.hpp: ~1.5 us against ~10 us), times R^3 = RSQ * RSQ / R
+static inline Fr fr_inv(const Fr& a)
+{
+    static const ModInfo info = modinfo_from(FrHostP::P);
+    static const Fr r3 = fr_mul(fr_from_limbs(FrHostP::RSQ), fr_from_limbs(FrHostP::RSQ));
+    Fr t;
+    modinv_u64x4(a.d, info, t.d);
+    return fr_mul(t, r3);
 }
 // plain integer (any 256-bit value) -> Montgomery form, reduced mod r
 static inline Fr fr_to_mont(const Fr& raw) { return fr_mul(raw, fr_from_limbs(FrHostP::RSQ)); }

@@ -48,6 +48,29 @@ int main()
             if (!winf && !ginf) CHECK(!memcmp(wn, got, 64), "msm_small mode %d n %zu", mode, n);
         }
     }
+    // ---- divsteps inversion = Fermat inversion, both fields: edge values and 20,000 random canonical values each
+    {
+        uint64_t st = 0x9e3779b97f4a7c15ULL;
+        auto next = [&]() { return orc_splitmix64(&st); };
+        const uint64_t* pq = orc_const(0, "modulus");
+        int bad_q = 0, bad_r = 0;
+        for (int i = 0; i < 20040; i++) {
+            Fq a; Fr b;
+            for (int l = 0; l < 4; l++) { a.d[l] = next(); b.d[l] = next(); }
+            a.d[3] &= 0x1fffffffffffffffULL; b.d[3] &= 0x1fffffffffffffffULL; // < 2^253 < p, r
+            if (i < 40) { // small values, p - small, powers of two
+                memset(a.d, 0, 32); memset(b.d, 0, 32);
+                if (i < 10) { a.d[0] = (uint64_t)i; b.d[0] = (uint64_t)i; }
+                else if (i < 20) { memcpy(a.d, pq, 32); a.d[0] -= (uint64_t)(i - 9); memcpy(b.d, r_mod, 32); b.d[0] -= (uint64_t)(i - 9); }
+                else { a.d[(i - 20) / 5] = 1ULL << (13 * ((i - 20) % 5)); b.d[(i - 20) / 5] = 1ULL << (12 * ((i - 20) % 5) + 1); }
+            }
+            const Fq ia = fq_inv(a), fa = fq_inv_fermat(a);
+            const Fr ib = fr_inv(b), fb = fr_inv_fermat(b);
+            if (memcmp(ia.d, fa.d, 32)) bad_q++;
+            if (memcmp(ib.d, fb.d, 32)) bad_r++;
+        }
+        CHECK(bad_q == 0 && bad_r == 0, "divsteps inversion differs from Fermat: fq %d fr %d of 20040", bad_q, bad_r);
+    }
     // ---- batch normalisation = one by one
     {
         Xyzz pts[8];
