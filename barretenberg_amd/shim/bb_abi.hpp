@@ -3,7 +3,7 @@
 // parameters, member order and alignments are an ABI necessity; no function bodies of the reference
 // appear here.  Sources of the layouts: fields/field.hpp:19-22 (field_t, alignas(32)), groups/group.hpp:17-28
 // (affine_element, element), polynomials/evaluation_domain.hpp:9-59 (member order),
-// curves/bn254/scalar_multiplication.hpp:88-94 (multiplication_state).
+// curves/bn254/scalar_multiplication.hpp:14-39 (the CPU algorithm's state structs), :88-94 (multiplication_state).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -65,6 +65,34 @@ struct multiplication_state {
     size_t num_elements;
     g1::element output;
 };
+// the CPU algorithm's own state (scalar_multiplication.hpp:14-39): member order is the ABI
+struct wnaf_runtime_state {
+    uint64_t current_sign;
+    uint64_t next_sign;
+    size_t current_idx;
+    size_t next_idx;
+    size_t bits_per_wnaf;
+    uint32_t* wnaf_iterator;
+    uint32_t* wnaf_table;
+    bool* skew_table;
+};
+struct multiplication_runtime_state {
+    size_t num_points;
+    size_t num_rounds;
+    size_t num_buckets;
+    size_t switch_point;
+    g1::element* buckets;
+    g1::affine_element addition_temporary;
+    g1::element accumulator;
+    g1::element running_sum;
+};
+void compute_next_bucket_index(wnaf_runtime_state& state);
+void compute_wnaf_state(multiplication_runtime_state& state, wnaf_runtime_state& wnaf_state, fr::field_t* scalars, size_t num_initial_points,
+                        fr::field_t* endo_scalars, size_t forced_bucket_width);
+g1::element pippenger_internal(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, fr::field_t* endo_scalars,
+                               size_t forced_bucket_width);
+g1::element alt_pippenger_internal(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, fr::field_t* endo_scalars,
+                                   size_t forced_bucket_width);
 g1::element pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width);
 void batched_scalar_multiplications(multiplication_state* mul_state, size_t num_batches);
 void generate_pippenger_point_table(g1::affine_element* points, g1::affine_element* table, size_t num_points);
@@ -109,6 +137,10 @@ static_assert(sizeof(fr::field_t) == 32 && alignof(fr::field_t) == 32, "field_t"
 static_assert(sizeof(g1::affine_element) == 64 && sizeof(g1::element) == 96, "g1 elements");
 static_assert(sizeof(scalar_multiplication::multiplication_state) == 128, "multiplication_state");
 static_assert(offsetof(scalar_multiplication::multiplication_state, output) == 32, "multiplication_state.output");
+static_assert(sizeof(scalar_multiplication::wnaf_runtime_state) == 64 && sizeof(scalar_multiplication::multiplication_runtime_state) == 320, "CPU Pippenger state");
+static_assert(offsetof(scalar_multiplication::multiplication_runtime_state, buckets) == 32 && offsetof(scalar_multiplication::multiplication_runtime_state, addition_temporary) == 64 &&
+                  offsetof(scalar_multiplication::multiplication_runtime_state, accumulator) == 128 && offsetof(scalar_multiplication::multiplication_runtime_state, running_sum) == 224,
+              "multiplication_runtime_state fields");
 static_assert(sizeof(evaluation_domain) == 320, "evaluation_domain");
 static_assert(offsetof(evaluation_domain, root) == 64 && offsetof(evaluation_domain, generator_inverse) == 224, "evaluation_domain fields");
 

@@ -19,9 +19,10 @@
 // :129-264 (forwarded to the GPU transform), scale_by_generator :81-102, compute_multiplicative_subgroup :104-127, add / mul :317-335
 // -- O(n) host loops on csrc/host_fr.hpp, canonical outputs.
 // plus pippenger_low_memory / alt_pippenger (same sum, same arguments).
-// Not defined: the CPU Pippenger's private machinery (compute_wnaf_state, compute_next_bucket_index, pippenger_internal,
-// alt_pippenger_internal) whose argument types are the CPU algorithm's own state structs, and the pippenger_precomputed family
-// (generate_pippenger_precompute_table hands back the CPU layout of per-round tables; the GPU keeps its own window tables resident).
+// Also defined (SURVEY 8b "the MSM shim should define"): the CPU Pippenger's own machinery -- compute_wnaf_state (the GLV split and digit table of
+// csrc/host_wnaf.hpp, host code), compute_next_bucket_index, pippenger_internal / alt_pippenger_internal (scalars already out of Montgomery form).
+// Not defined: the pippenger_precomputed family (generate_pippenger_precompute_table hands back the CPU layout of per-round tables; the GPU keeps
+// its own window tables resident).
 //
 // Error behaviour: the reference API has no error channel.  A failing GPU call prints the library's error
 // and aborts: silently returning a wrong proof element is worse than stopping, and there is deliberately no CPU
@@ -34,6 +35,7 @@
 
 #include "../../include/bbgpu.h"
 #include "../csrc/host_fr.hpp"
+#include "../csrc/host_wnaf.hpp"
 
 namespace {
 [[noreturn]] void die(const char* what, int rc)
@@ -95,6 +97,71 @@ size_t get_optimal_bucket_width(const size_t num_points)
     for (const auto& row : table)
         if (num_points >= row.at_least) return row.width;
     return 1;
+}
+
+// ---- the CPU Pippenger's own machinery (no caller outside the translation unit in src/; the reference's tests and benches link it) --------------
+// scalar_multiplication.cpp:83-88: the next digit-table entry, split into sign and bucket index
+void compute_next_bucket_index(wnaf_runtime_state& state)
+{
+    const uint32_t entry = *state.wnaf_iterator;
+    state.next_sign = (entry >> 31) & 1;
+    state.next_idx = entry & 0x0fffffffU;
+}
+// :265-308: allocates the bucket array (2^c elements at infinity), the digit table (rounds x 2n entries, consecutive digits of one scalar 2n apart,
+// most significant round first) and the skew bits, and fills them from the GLV halves of every scalar (written to endo_scalars[i].data[0..1] and
+// [2..3]).  `scalars` are plain integers (the caller has left Montgomery form, :468-472).  The caller owns and frees the three arrays.
+void compute_wnaf_state(multiplication_runtime_state& state, wnaf_runtime_state& wnaf_state, fr::field_t* scalars, size_t num_initial_points,
+                        fr::field_t* endo_scalars, size_t forced_bucket_width)
+{
+    using namespace bbgpu::host;
+    const size_t bits = forced_bucket_width > 0 ? forced_bucket_width : get_optimal_bucket_width(num_initial_points);
+    state.num_points = 2 * num_initial_points;
+    state.num_rounds = wnaf_size(bits + 1);
+    state.num_buckets = (size_t)1 << bits;
+    wnaf_state.bits_per_wnaf = bits + 1;
+    auto round32 = [](size_t bytes) { return (bytes + 31) & ~(size_t)31; };
+    state.buckets = static_cast<g1::element*>(aligned_alloc(32, round32(sizeof(g1::element) * state.num_buckets)));
+    for (size_t i = 0; i < state.num_buckets; ++i) state.buckets[i].y.data[3] = 1ULL << 63; // set_infinity: the flag bit, nothing else (group.hpp:133-151)
+    wnaf_state.wnaf_table = static_cast<uint32_t*>(aligned_alloc(32, round32(sizeof(uint32_t) * (state.num_rounds * state.num_points + 1))));
+    wnaf_state.skew_table = static_cast<bool*>(aligned_alloc(32, round32(state.num_points + 1)));
+    if (!state.buckets || !wnaf_state.wnaf_table || !wnaf_state.skew_table) die("compute_wnaf_state (allocation)", BBGPU_ERR_HIP);
+    for (size_t i = 0; i < num_initial_points; ++i) {
+        uint64_t k[4], k1[2], k2[2];
+        memcpy(k, scalars[i].data, 32); // endo_scalars may alias scalars
+        split_endo(k, k1, k2);
+        endo_scalars[i].data[0] = k1[0]; endo_scalars[i].data[1] = k1[1];
+        endo_scalars[i].data[2] = k2[0]; endo_scalars[i].data[3] = k2[1];
+        fixed_wnaf(k1, &wnaf_state.wnaf_table[2 * i], wnaf_state.skew_table[2 * i], state.num_points, bits + 1);
+        fixed_wnaf(k2, &wnaf_state.wnaf_table[2 * i + 1], wnaf_state.skew_table[2 * i + 1], state.num_points, bits + 1);
+    }
+    state.accumulator.y.data[3] = 1ULL << 63;
+    wnaf_state.wnaf_iterator = wnaf_state.wnaf_table;
+    compute_next_bucket_index(wnaf_state);
+}
+// :576-648 / alt: sum_i k_i P_i for scalars that have ALREADY left Montgomery form (`pippenger` converts and calls this, :468-474); `points` is the
+// 2n-entry endomorphism table.  The sum is computed by the GPU path, which takes Montgomery scalars: one host multiplication by R^2 per scalar.
+// endo_scalars (the CPU algorithm's scratch for the split scalars, usually the same array) is left as it is.
+g1::element pippenger_internal(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, fr::field_t* /*endo_scalars*/,
+                               size_t forced_bucket_width)
+{
+    using namespace bbgpu::host;
+    if (num_initial_points == 0) return pippenger(scalars, points, 0, forced_bucket_width);
+    fr::field_t* mont = static_cast<fr::field_t*>(aligned_alloc(32, sizeof(fr::field_t) * num_initial_points));
+    if (!mont) die("pippenger_internal (allocation)", BBGPU_ERR_HIP);
+    for (size_t i = 0; i < num_initial_points; ++i) {
+        Fr k;
+        memcpy(k.d, scalars[i].data, 32);
+        k = fr_to_mont(k);
+        memcpy(mont[i].data, k.d, 32);
+    }
+    g1::element out = pippenger(mont, points, num_initial_points, forced_bucket_width);
+    free(mont);
+    return out;
+}
+g1::element alt_pippenger_internal(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, fr::field_t* endo_scalars,
+                                   size_t forced_bucket_width)
+{
+    return pippenger_internal(scalars, points, num_initial_points, endo_scalars, forced_bucket_width);
 }
 
 } // namespace scalar_multiplication

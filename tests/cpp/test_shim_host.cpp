@@ -1,12 +1,15 @@
 // Host-only members of the shim (barretenberg_amd/shim/bb_shim.cpp): the translation units' remaining externs that the PLONK stack
-// never calls (get_optimal_bucket_width, scale_by_generator, compute_multiplicative_subgroup, add, mul, fft_inner_serial).
+// never calls (get_optimal_bucket_width, scale_by_generator, compute_multiplicative_subgroup, add, mul, fft_inner_serial, compute_wnaf_state,
+// compute_next_bucket_index).
 // Prints their outputs on seeded inputs as hex; tests/test_host_boundary.py compares with the oracle.  Links libbbshim.so; no GPU.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../../barretenberg_amd/shim/bb_abi.hpp"
 #include "../../barretenberg_amd/csrc/host_fr.hpp"
+#include "../../barretenberg_amd/csrc/host_g1.hpp"
 
 using namespace barretenberg;
 using bbgpu::host::Fr;
@@ -76,5 +79,87 @@ int main()
     r = a;
     polynomial_arithmetic::fft_inner_serial(r.data(), n, table);
     dump("fft_serial", r.data(), n);
+    // the CPU Pippenger's scalar preparation (scalar_multiplication.cpp:265-308) on 40 plain (non-Montgomery) scalars below r, two bucket widths:
+    // split scalars, the whole digit table, the skew bits, the bookkeeping fields; then the iterator protocol of compute_next_bucket_index
+    {
+        const size_t m = 40;
+        std::vector<fr::field_t> k(m), endo(m);
+        fill(k, 44);
+        for (auto& e : k) e.data[3] &= 0x0fffffffffffffffULL; // < 2^252 < r: the caller hands canonical plain integers
+        k[0].data[0] &= ~1ULL;                                 // an even and an odd scalar for the skew bit
+        k[1].data[0] |= 1ULL;
+        dump("k", k.data(), m);
+        for (size_t width : { 0ul, 7ul }) {
+            scalar_multiplication::multiplication_runtime_state st;
+            scalar_multiplication::wnaf_runtime_state ws;
+            std::memset(&st, 0, sizeof st);
+            std::memset(&ws, 0, sizeof ws);
+            scalar_multiplication::compute_wnaf_state(st, ws, k.data(), m, endo.data(), width);
+            std::printf("wnafstate %zu %zu %zu %zu %zu\n", width, st.num_points, st.num_rounds, st.num_buckets, ws.bits_per_wnaf);
+            char tag[32];
+            std::snprintf(tag, sizeof tag, "endo%zu", width);
+            dump(tag, endo.data(), m);
+            for (size_t r0 = 0; r0 < st.num_rounds; r0++) {
+                std::printf("wnaf%zu %zu", width, r0);
+                for (size_t j = 0; j < st.num_points; j++) std::printf(" %08x", ws.wnaf_table[r0 * st.num_points + j]);
+                std::printf("\n");
+            }
+            std::printf("skew%zu 0", width);
+            for (size_t j = 0; j < st.num_points; j++) std::printf(" %d", (int)ws.skew_table[j]);
+            std::printf("\n");
+            bool inf = true;
+            for (size_t b = 0; b < st.num_buckets; b++) inf = inf && (st.buckets[b].y.data[3] >> 63);
+            std::printf("state%zu 0 %d %d %lu %lu\n", width, (int)inf, (int)(st.accumulator.y.data[3] >> 63), (unsigned long)ws.next_sign, (unsigned long)ws.next_idx);
+            ws.wnaf_iterator = ws.wnaf_table + 5;
+            scalar_multiplication::compute_next_bucket_index(ws);
+            std::printf("iter%zu 0 %lu %lu %08x\n", width, (unsigned long)ws.next_sign, (unsigned long)ws.next_idx, ws.wnaf_table[5]);
+            free(st.buckets);
+            free(ws.wnaf_table);
+            free(ws.skew_table);
+        }
+    }
+    // pippenger_internal / alt_pippenger_internal (:576-648): plain scalars in, the same group element as pippenger() on their Montgomery forms.
+    // 16 points i * G built with the library's host arithmetic (csrc/host_g1.hpp), so the expected sum is (sum_i k_i i) * G: checked here, "pipint ok".
+    {
+        using namespace bbgpu::host;
+        const size_t m = 16;
+        Fq gx = FQ_ONE, gy = fq_dbl(FQ_ONE); // the generator (1, 2) in Montgomery form (g1.hpp:14-16)
+        Xyzz G = { gx, gy, FQ_ONE, FQ_ONE }, run = G;
+        std::vector<g1::affine_element> pts(m), tab(2 * m);
+        for (size_t i = 0; i < m; i++) {
+            uint64_t nrm[12];
+            g1_to_normalised(run, nrm);
+            std::memcpy(pts[i].x.data, nrm, 32);
+            std::memcpy(pts[i].y.data, nrm + 4, 32);
+            run = g1_add(run, G);
+        }
+        scalar_multiplication::generate_pippenger_point_table(pts.data(), tab.data(), m);
+        std::vector<fr::field_t> k(m), km(m), scratch(m);
+        fill(k, 55);
+        Fr sum = fr_zero();
+        for (size_t i = 0; i < m; i++) {
+            k[i].data[3] &= 0x0fffffffffffffffULL;
+            Fr ki;
+            std::memcpy(ki.d, k[i].data, 32);
+            const Fr kmont = fr_to_mont(ki);
+            std::memcpy(km[i].data, kmont.d, 32);
+            sum = fr_add(sum, fr_mul(kmont, fr_from_u64(i + 1)));
+        }
+        const Fr s_plain = fr_from_mont(sum);
+        Xyzz want = g1_infinity();
+        for (int bit = 255; bit >= 0; --bit) {
+            want = g1_dbl(want);
+            if ((s_plain.d[bit >> 6] >> (bit & 63)) & 1) want = g1_add(want, G);
+        }
+        uint64_t wn[12];
+        g1_to_normalised(want, wn);
+        scratch = k;
+        const g1::element a = scalar_multiplication::pippenger_internal(scratch.data(), tab.data(), m, scratch.data(), 0);
+        scratch = k;
+        const g1::element b = scalar_multiplication::alt_pippenger_internal(scratch.data(), tab.data(), m, scratch.data(), 5);
+        const g1::element c = scalar_multiplication::pippenger(km.data(), tab.data(), m, 0);
+        const bool ok = !std::memcmp(a.x.data, wn, 32) && !std::memcmp(a.y.data, wn + 4, 32) && !std::memcmp(&a, &c, 96) && !std::memcmp(&b, &c, 96);
+        std::printf("pipint %s\n", ok ? "ok" : "MISMATCH");
+    }
     return 0;
 }

@@ -169,11 +169,16 @@ def test_shim_host_members_match_oracle(oracle):
         subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shim_host.cpp"), "-L" + pkg, "-lbbshim", "-lbbgpu",
                         "-Wl,-rpath," + pkg], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0")).stdout
-    vec, width = {}, {}
+    assert "pipint ok" in out
+    vec, width, raw = {}, {}, {}
     for line in out.splitlines():
         t = line.split()
         if t[0] == "width":
             width[int(t[1])] = int(t[2])
+        elif t[0] == "pipint":
+            assert t[1] == "ok", "pippenger_internal / alt_pippenger_internal differ from pippenger() or from (sum k_i i) G"
+        elif t[0].startswith(("wnaf", "skew", "state", "iter")):
+            raw.setdefault(t[0], []).append(t[1:])
         else:
             vec.setdefault(t[0], []).append(np.array([int(x, 16) for x in t[2:6]], dtype=np.uint64))
     for n, w in width.items():
@@ -197,12 +202,34 @@ def test_shim_host_members_match_oracle(oracle):
         assert np.array_equal(vec["subgroup"][i], canon(acc)), i
         acc = oracle.mul(FR, acc, root)
     assert np.array_equal(np.stack(vec["fft_serial"]), oracle.ntt(a, "fft"))  # :37-79 computes the same transform as fft()
+    # compute_wnaf_state / compute_next_bucket_index (scalar_multiplication.cpp:83-88, 265-308) against the oracle's split and digit functions
+    # (pinned by the reference's own vectors, tests/golden/endo_wnaf.json)
+    k = np.stack(vec["k"])
+    m = k.shape[0]
+    for forced in (0, 7):
+        bits = forced or oracle.optimal_bucket_width(m)
+        rounds = (127 + bits) // (bits + 1)
+        assert [int(x) for x in raw["wnafstate"][[0, 7].index(forced)]] == [forced, 2 * m, rounds, 1 << bits, bits + 1]
+        table = np.array([[int(x, 16) for x in row[1:]] for row in raw["wnaf%d" % forced]], dtype=np.uint32)
+        skew = [int(x) for x in raw["skew%d" % forced][0][1:]]
+        endo = np.stack(vec["endo%d" % forced])
+        assert table.shape == (rounds, 2 * m)
+        for i in range(m):
+            k1, k2 = oracle.split_endo(k[i])
+            assert np.array_equal(endo[i][:2], k1) and np.array_equal(endo[i][2:], k2), i
+            for half, kk in enumerate((k1, k2)):
+                want, want_skew = oracle.fixed_wnaf(kk, bits + 1)
+                assert np.array_equal(table[:, 2 * i + half], want), (forced, i, half)
+                assert skew[2 * i + half] == want_skew
+        first = int(table[0, 0])
+        assert [int(x) for x in raw["state%d" % forced][0]] == [0, 1, 1, first >> 31, first & 0x0fffffff]
+        e5 = int(table[0, 5])
+        assert raw["iter%d" % forced][0][1:3] == [str(e5 >> 31), str(e5 & 0x0fffffff)] and int(raw["iter%d" % forced][0][3], 16) == e5
 
 
 def test_shim_covers_the_replaced_translation_units():
     """INTEGRATION recipe A replaces two whole translation units: every extern of polynomial_arithmetic.o is defined by the shim, and
-    of scalar_multiplication.o everything except the CPU algorithm's private machinery (state structs of its own) and the
-    pippenger_precomputed family.  Compared against the reference objects compiled in place (oracle/_ref/obj; skipped where absent)."""
+    of scalar_multiplication.o everything except the pippenger_precomputed family (the CPU layout of per-round tables).  Compared against the reference objects compiled in place (oracle/_ref/obj; skipped where absent)."""
     obj = os.path.join(ROOT, "oracle", "_ref", "obj")
     pa, sm = os.path.join(obj, "polynomials", "polynomial_arithmetic.o"), os.path.join(obj, "curves", "bn254", "scalar_multiplication.o")
     if not (os.path.exists(pa) and os.path.exists(sm)):
@@ -215,8 +242,7 @@ def test_shim_covers_the_replaced_translation_units():
     shim = externs(os.path.join(ROOT, "barretenberg_amd", "libbbshim.so"), dynamic=True)
     assert externs(pa) <= shim, sorted(externs(pa) - shim)
     missing = externs(sm) - shim
-    allowed = ("compute_wnaf_state", "compute_next_bucket_index", "pippenger_internal", "alt_pippenger_internal", "pippenger_precomputed",
-               "pippenger_internal_precomputed", "generate_pippenger_precompute_table")
+    allowed = ("pippenger_precomputed", "pippenger_internal_precomputed", "generate_pippenger_precompute_table")
     for m in missing:
         assert any(a in m for a in allowed), m
     assert len(externs(sm) & shim) >= 6
