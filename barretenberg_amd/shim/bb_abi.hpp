@@ -94,6 +94,10 @@ g1::element pippenger_internal(fr::field_t* scalars, g1::affine_element* points,
 g1::element alt_pippenger_internal(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, fr::field_t* endo_scalars,
                                    size_t forced_bucket_width);
 g1::element pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width);
+std::vector<g1::affine_element*> generate_pippenger_precompute_table(g1::affine_element* points, g1::affine_element* table, size_t num_points, size_t bits_per_bucket);
+g1::element pippenger_internal_precomputed(fr::field_t* scalars, const std::vector<g1::affine_element*>& round_points, const size_t num_initial_points,
+                                           fr::field_t* endo_scalars);
+g1::element pippenger_precomputed(fr::field_t* scalars, const std::vector<g1::affine_element*>& round_points, const size_t num_initial_points);
 void batched_scalar_multiplications(multiplication_state* mul_state, size_t num_batches);
 void generate_pippenger_point_table(g1::affine_element* points, g1::affine_element* table, size_t num_points);
 size_t get_optimal_bucket_width(const size_t num_points);

@@ -21,8 +21,8 @@
 // plus pippenger_low_memory / alt_pippenger (same sum, same arguments).
 // Also defined (SURVEY 8b "the MSM shim should define"): the CPU Pippenger's own machinery -- compute_wnaf_state (the GLV split and digit table of
 // csrc/host_wnaf.hpp, host code), compute_next_bucket_index, pippenger_internal / alt_pippenger_internal (scalars already out of Montgomery form).
-// Not defined: the pippenger_precomputed family (generate_pippenger_precompute_table hands back the CPU layout of per-round tables; the GPU keeps
-// its own window tables resident).
+// and the pippenger_precomputed family (generate_pippenger_precompute_table fills the CPU layout of per-round tables as host code; the sums ignore them:
+// the GPU keeps its own window tables resident).  Every extern of both replaced translation units is defined.
 //
 // Error behaviour: the reference API has no error channel.  A failing GPU call prints the library's error
 // and aborts: silently returning a wrong proof element is worse than stopping, and there is deliberately no CPU
@@ -35,6 +35,7 @@
 
 #include "../../include/bbgpu.h"
 #include "../csrc/host_fr.hpp"
+#include "../csrc/host_g1.hpp"
 #include "../csrc/host_wnaf.hpp"
 
 namespace {
@@ -162,6 +163,60 @@ g1::element alt_pippenger_internal(fr::field_t* scalars, g1::affine_element* poi
                                    size_t forced_bucket_width)
 {
     return pippenger_internal(scalars, points, num_initial_points, endo_scalars, forced_bucket_width);
+}
+
+// :90-129: per-round copies of a point table for the CPU algorithm's precomputed variant -- table[i * num_points + j] = 2^((c + 1)(i + 1)) * points[j],
+// affine, i < rounds - 1; returns the tables most significant round first with `points` itself last.  Host code (host_g1.hpp doublings, one inversion per
+// round): like the reference's, a one-off of rounds * (c + 1) doublings per point.  The GPU path keeps its own window tables and never reads these.
+std::vector<g1::affine_element*> generate_pippenger_precompute_table(g1::affine_element* points, g1::affine_element* table, size_t num_points,
+                                                                     size_t bits_per_bucket)
+{
+    using namespace bbgpu::host;
+    const size_t rounds = wnaf_size(bits_per_bucket + 1);
+    std::vector<Xyzz> cur(num_points);
+    std::vector<Fq> den(num_points), pre(num_points);
+    for (size_t j = 0; j < num_points; ++j) {
+        memcpy(cur[j].x.d, points[j].x.data, 32);
+        memcpy(cur[j].y.d, points[j].y.data, 32);
+        cur[j].zz = FQ_ONE;
+        cur[j].zzz = FQ_ONE;
+    }
+    for (size_t i = 0; i + 1 < rounds; ++i) {
+        Fq run = FQ_ONE;
+        for (size_t j = 0; j < num_points; ++j) {
+            for (size_t k = 0; k < bits_per_bucket + 1; ++k) cur[j] = g1_dbl(cur[j]);
+            pre[j] = run;
+            den[j] = fq_mul(cur[j].zz, cur[j].zzz); // never zero: the points have prime order
+            run = fq_mul(run, den[j]);
+        }
+        Fq inv = num_points ? fq_inv(run) : FQ_ONE;
+        g1::affine_element* out = &table[i * num_points];
+        for (size_t j = num_points; j-- > 0;) {
+            const Fq dj = fq_mul(inv, pre[j]); // 1 / (zz zzz)
+            inv = fq_mul(inv, den[j]);
+            const Fq x = fq_mul(cur[j].x, fq_mul(dj, cur[j].zzz)), y = fq_mul(cur[j].y, fq_mul(dj, cur[j].zz));
+            memcpy(out[j].x.data, x.d, 32);
+            memcpy(out[j].y.data, y.d, 32);
+            cur[j].x = x;
+            cur[j].y = y;
+            cur[j].zz = FQ_ONE;
+            cur[j].zzz = FQ_ONE;
+        }
+    }
+    std::vector<g1::affine_element*> result(rounds);
+    result[rounds - 1] = points;
+    for (size_t i = 0; i + 1 < rounds; ++i) result[rounds - 2 - i] = &table[i * num_points];
+    return result;
+}
+// :478-574: the same sum as pippenger() -- the last entry of round_points is the plain point table
+g1::element pippenger_internal_precomputed(fr::field_t* scalars, const std::vector<g1::affine_element*>& round_points, const size_t num_initial_points,
+                                           fr::field_t* endo_scalars)
+{
+    return pippenger_internal(scalars, round_points.back(), num_initial_points, endo_scalars, 0);
+}
+g1::element pippenger_precomputed(fr::field_t* scalars, const std::vector<g1::affine_element*>& round_points, const size_t num_initial_points)
+{
+    return pippenger(scalars, round_points.back(), num_initial_points, 0);
 }
 
 } // namespace scalar_multiplication

@@ -160,6 +160,27 @@ int main()
         const g1::element c = scalar_multiplication::pippenger(km.data(), tab.data(), m, 0);
         const bool ok = !std::memcmp(a.x.data, wn, 32) && !std::memcmp(a.y.data, wn + 4, 32) && !std::memcmp(&a, &c, 96) && !std::memcmp(&b, &c, 96);
         std::printf("pipint %s\n", ok ? "ok" : "MISMATCH");
+        // the precomputed family (:90-129, :478-574): per-round tables 2^(4 (i + 1)) P_j for c = 3, and the same sum through them
+        std::vector<g1::affine_element> pre(31 * 2 * m);
+        const std::vector<g1::affine_element*> rp = scalar_multiplication::generate_pippenger_precompute_table(tab.data(), pre.data(), 2 * m, 3);
+        std::printf("prerounds 0 %zu %d %d\n", rp.size(), (int)(rp.back() == tab.data()), (int)(rp.size() > 1 && rp[rp.size() - 2] == pre.data()));
+        for (size_t i : { 0ul, 1ul, 30ul })
+            for (size_t j : { 0ul, 1ul, 31ul }) {
+                std::printf("pre %zu %zu", i, j);
+                for (int l = 0; l < 4; l++) std::printf(" %016lx", pre[i * 2 * m + j].x.data[l]);
+                for (int l = 0; l < 4; l++) std::printf(" %016lx", pre[i * 2 * m + j].y.data[l]);
+                std::printf("\n");
+            }
+        for (size_t j : { 0ul, 1ul, 31ul }) {
+            std::printf("base 0 %zu", j);
+            for (int l = 0; l < 4; l++) std::printf(" %016lx", tab[j].x.data[l]);
+            for (int l = 0; l < 4; l++) std::printf(" %016lx", tab[j].y.data[l]);
+            std::printf("\n");
+        }
+        scratch = k;
+        const g1::element d = scalar_multiplication::pippenger_internal_precomputed(scratch.data(), rp, m, scratch.data());
+        const g1::element e = scalar_multiplication::pippenger_precomputed(km.data(), rp, m);
+        std::printf("pippre %s\n", (!std::memcmp(&d, &c, 96) && !std::memcmp(&e, &c, 96)) ? "ok" : "MISMATCH");
     }
     return 0;
 }
