@@ -30,8 +30,25 @@ class PartialSumExchange:
             self.done = [torch.cuda.Event() for _ in range(self.RING)]
         else:
             self.send_d, self.recv_d = self.send_h, self.recv_h
-        self.flat = hasattr(dist, "all_gather_into_tensor")
+        # flat (all_gather_into_tensor) or list form: settled ONCE here, by a collective every rank runs in the same order, and agreed by a
+        # MIN all-reduce -- never per step, where one rank falling back alone would pair a flat call with a list call
+        self.flat = self._settle_flat()
         self.count = 0
+
+    def _settle_flat(self):
+        ok = 0
+        if hasattr(dist, "all_gather_into_tensor"):
+            try:
+                work = dist.all_gather_into_tensor(self.recv_d[0], self.send_d[0].zero_(), async_op=True)
+                work.wait()
+                if self.on_gpu:
+                    torch.cuda.synchronize(self.device)
+                ok = 1
+            except (RuntimeError, NotImplementedError):  # a backend without the flat form raises before it communicates, on every rank alike
+                ok = 0
+        t = torch.tensor([ok], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
 
     def start(self, part):
         k = self.count % self.RING
@@ -39,13 +56,9 @@ class PartialSumExchange:
         self.send_h[k].numpy()[:] = np.ascontiguousarray(part, dtype=np.uint64).view(np.int64)
         if self.on_gpu:
             self.send_d[k].copy_(self.send_h[k], non_blocking=True)
-        work = None
         if self.flat:
-            try:
-                work = dist.all_gather_into_tensor(self.recv_d[k], self.send_d[k], async_op=True)
-            except (RuntimeError, NotImplementedError):  # a backend without the flat form
-                self.flat = False
-        if work is None:
+            work = dist.all_gather_into_tensor(self.recv_d[k], self.send_d[k], async_op=True)
+        else:
             work = dist.all_gather(list(self.recv_d[k].view(self.world, 12).unbind(0)), self.send_d[k], async_op=True)
         return work, k
 

@@ -5,10 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one 2^20-point MSM (random 253-bit scalars against the resident synthetic SRS x^i G) through the C ABI of
-libbbgpu.so with inputs already in HBM, result normalised on the host.  With N > 1 ranks the MSM's digit windows are
-sharded over the ranks (north star): every rank accumulates its window range of the SAME MSM, partial sums (96 bytes
-per rank) are exchanged with one RCCL all-gather and folded on every rank -> "strong" scaling.  The NTT leg (single
-GPU by design) is timed the same way on rank 0's GPU and reported in the "ntt" object of the same JSON line.
+libbbgpu.so with inputs already in HBM, result normalised on the host.  With N > 1 ranks the MSM is sharded over the
+ranks (north star): every rank accumulates its share of the SAME MSM, partial sums (96 bytes per rank) are exchanged
+with one RCCL all-gather and folded on every rank -> "strong" scaling.  The NTT leg (single GPU by design) is timed the
+same way on rank 0's GPU and reported in the "ntt" object of the same JSON line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF: the parent below
+never imports torch or touches HIP, it starts N fresh child processes of this file with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT set (one rank per GPU), lets rank 0's JSON line through on its own stdout, and exits non-zero
+if any child did (the other ranks are then ended by their exact PIDs).  Under torch.distributed.run the ranks already
+exist and the file runs as one of them.
 
 Only the cpu_baseline leg touches oracle/ (the reference's own code compiled into oracle/_ref, timed on the host).
 """
@@ -17,6 +23,65 @@ import json
 import os
 import sys
 import time
+
+
+def launch_ranks(argv):
+    """Parent side of `bench.py --gpus N`: returns None when this process is itself a rank (N == 1, or a launcher already set
+    WORLD_SIZE), else the exit code of the N-rank job it ran.  Nothing here may import torch or load the HIP library: a process
+    that has initialised the GPU must not be the one that starts the ranks."""
+    import signal
+    import socket
+    import subprocess
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=None)
+    known, _ = ap.parse_known_args(argv)
+    n = known.gpus or 1
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                BBGPU_BENCH_LAUNCHER_PID=str(os.getpid()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=dict(base, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(n)]
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    print("bench.py: rank %d exited with %d, ending the other ranks" % (r, code), file=sys.stderr, flush=True)
+                    for o in sorted(live):
+                        procs[o].terminate()  # exact PIDs of the children started above
+            if live:
+                time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
+
+
+if __name__ == "__main__":
+    _rc = launch_ranks(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
 
 import numpy as np
 import torch
@@ -220,7 +285,7 @@ def ntt_roofline(n, device_ms, traffic):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; N > 1 without a launcher starts the N ranks itself (launch_ranks)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2n", type=int, default=LOG2N)
@@ -230,19 +295,50 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (host-pointer, PCIe) legs, the 2^22 transforms and config 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
+    ap.add_argument("--probe", action="store_true", help="no GPU work: form the process group of the N ranks, report who is there, exit (launch check)")
+    ap.add_argument("--shard", default="rows", choices=("buckets", "rows", "windows"),
+                    help="N > 1: how one MSM is split over the ranks (buckets: every rank reduces 1/N of the bucket range over all windows; "
+                         "rows: 1/N of the (window, point) table rows; windows: whole digit windows)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is None:
+        args.gpus = world
+    if world != args.gpus:  # launch_ranks() makes them equal; a foreign launcher must agree with the flag
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or under torch.distributed.run with --nproc-per-node N" % (args.gpus, world),
+              file=sys.stderr)
+        sys.exit(2)
     if args.same_device:
         local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if args.backend == "nccl" and not args.probe:
+            have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+            if have <= local_rank:
+                print("bench.py: rank %d needs cuda:%d, this node shows %d GPU(s)" % (rank, local_rank, have), file=sys.stderr)
+                sys.exit(3)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo" if args.probe else args.backend, rank=rank, world_size=world)
+    if args.probe:
+        # who is there: every rank's (rank, pid, parent pid) through one all-gather of the group the timed run would use
+        mine = torch.tensor([rank, os.getpid(), os.getppid()], dtype=torch.int64)
+        seen = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(seen, mine)
+        else:
+            seen = [mine]
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                              "ranks": [int(t[0]) for t in seen], "pids": [int(t[1]) for t in seen], "parent_pids": [int(t[2]) for t in seen],
+                              "launcher_pid": int(os.environ.get("BBGPU_BENCH_LAUNCHER_PID", "0"))}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        fail = os.environ.get("BBGPU_BENCH_PROBE_FAIL_RANK")
+        sys.exit(7 if fail is not None and int(fail) == rank else 0)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     G = BbGpu(device=local_rank)
@@ -489,6 +585,8 @@ def main():
             "value": n / (msm_ms * 1e-3),
             "unit": "points/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "exchange_backend": (args.backend if world > 1 else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": msm_ms,

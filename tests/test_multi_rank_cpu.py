@@ -114,3 +114,52 @@ def test_pipelined_async_exchange_over_gloo():
         p.join(timeout=300)
         assert p.exitcode == 0
     assert ret.get(timeout=10) == 1
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus N` (the driver's command form) with no launcher around it: the parent starts N fresh rank processes before
+    anything touches torch / HIP, the ranks form ONE process group of size N, rank 0's line comes through the parent's stdout"""
+    r, lines = _run_bench(["--gpus", "3", "--probe"])
+    assert r.returncode == 0, r.stderr
+    assert len(lines) == 1
+    p = lines[0]
+    assert p["n_gpus"] == 3 and p["rccl_ranks"] == 3 and p["ranks"] == [0, 1, 2]
+    assert len(set(p["pids"])) == 3 and p["launcher_pid"] not in p["pids"]
+    assert p["parent_pids"] == [p["launcher_pid"]] * 3  # children of the launcher, not re-executions of it
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    r, lines = _run_bench(["--gpus", "2", "--probe"], {"BBGPU_BENCH_PROBE_FAIL_RANK": "1"})
+    assert r.returncode == 7 and "rank 1 exited with 7" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_contradicts_the_flag():
+    r, lines = _run_bench(["--gpus", "4", "--probe"], {"WORLD_SIZE": "2", "RANK": "0", "MASTER_PORT": "29999"})
+    assert r.returncode == 2 and not lines and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_under_torch_distributed_run():
+    """the driver's N > 1 form: torch.distributed.run starts the ranks, bench.py must not start more"""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    port = 32500 + (os.getpid() % 2000)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--probe"], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and lines[0]["launcher_pid"] == 0
