@@ -34,7 +34,7 @@ NTT_KINDS = {
 C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
     "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
-    "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_transcript_write", "bbgpu_msm_g1",
+    "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_transcript_write", "bbgpu_msm_g1", "bbgpu_msm_g1_plain",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_set_table_share", "bbgpu_selftest_field", "bbgpu_selftest_g1",
@@ -92,6 +92,7 @@ class BbGpu:
         L.bbgpu_srs_register.argtypes = [u64p, C.c_size_t]
         L.bbgpu_srs_generate.argtypes = [u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1.argtypes = [u64p, u64p, C.c_size_t, u64p]
+        L.bbgpu_msm_g1_plain.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1_batch.argtypes = [C.POINTER(MsmJob), C.c_size_t]
         L.bbgpu_msm_num_windows.argtypes = [C.c_size_t]
         L.bbgpu_srs_num_windows.argtypes = [C.c_int, C.c_size_t]
@@ -231,6 +232,13 @@ class BbGpu:
         n = scalars.shape[0] if n is None else n
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.lib.bbgpu_msm_g1(_ptr(scalars), _ptr(points_endo_table), n, _ptr(out)))
+        return out
+
+    def pippenger_low_memory(self, scalars, points, n=None):
+        """scalar_multiplication::pippenger_low_memory (:142-262): `points` is the PLAIN n-entry table (n x 8 u64), not the endo table"""
+        n = scalars.shape[0] if n is None else n
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(self.lib.bbgpu_msm_g1_plain(_ptr(scalars), _ptr(points), n, _ptr(out)))
         return out
 
     def batched_scalar_multiplications(self, jobs):

@@ -45,6 +45,8 @@ struct SrsEntry {
     bool auto_registered = false; // created by a host-pointer MSM on first sight: evictable (stale contents, overlap, LRU under the byte cap)
     uint64_t last_use = 0;
     size_t bytes = 0; // device bytes held (points + window tables)
+    bool handle_exposed = false; // the index was returned to a caller as a handle: the slot is never reused for another table
+    uint64_t check_phase = 0;    // rotates the rows a content check samples (contents_match)
 };
 
 inline uint64_t hash_row(const uint64_t* row8)
@@ -234,6 +236,15 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
         e.tab_wb = twb;
         e.tab_we = twe;
     }
+    e.handle_exposed = !auto_registered;
+    // a long-lived process that keeps re-registering tables on first sight must not grow the registry by one entry per eviction: dead slots
+    // whose index no caller ever held are taken again
+    if (auto_registered)
+        for (size_t k = 0; k < g_ctx.srs.size(); k++)
+            if (!g_ctx.srs[k].live && !g_ctx.srs[k].handle_exposed) {
+                g_ctx.srs[k] = std::move(e);
+                return (int)k;
+            }
     g_ctx.srs.push_back(std::move(e));
     return (int)g_ctx.srs.size() - 1;
 }
@@ -254,14 +265,22 @@ int issue_on_entry(MsmSlot& S, const SrsEntry& e, size_t off, const uint64_t* d_
 }
 
 // does the host range [points, points + n) still hold what entry e was uploaded from (rows off .. off + n)?
-bool contents_match(const SrsEntry& e, size_t off, const uint64_t* points, size_t n)
+// 16 rows per check: the first, the last, and 14 evenly spaced ones whose PHASE moves on with every check of this entry, so that a buffer
+// rewritten only in the middle (a slice the fixed sample never touched) is caught within a few calls instead of never; the residual window
+// (a partial in-place rewrite is served stale until a sampled row falls into it) is stated in include/bbgpu.h.
+bool contents_match(SrsEntry& e, size_t off, const uint64_t* points, size_t n)
 {
     if (e.row_hash.size() != e.n) return false;
-    const size_t samples = n <= 16 ? n : 16;
-    for (size_t k = 0; k < samples; k++) {
-        const size_t i = samples == n ? k : (size_t)(((unsigned __int128)k * (n - 1)) / (samples - 1));
-        if (hash_row(points + i * 16) != e.row_hash[off + i]) return false;
+    auto same = [&](size_t i) { return hash_row(points + i * 16) == e.row_hash[off + i]; };
+    if (n <= 16) {
+        for (size_t i = 0; i < n; i++)
+            if (!same(i)) return false;
+        return true;
     }
+    if (!same(0) || !same(n - 1)) return false;
+    const size_t stride = n / 14, phase = (size_t)((e.check_phase++ * 0x9e3779b97f4a7c15ULL) % stride);
+    for (size_t k = 0; k < 14; k++)
+        if (!same(phase + k * stride)) return false;
     return true;
 }
 
@@ -299,7 +318,10 @@ int log2_exact(size_t n)
     return l;
 }
 
-int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12])
+// plain: `points` is an n-entry table of plain affine points (64 bytes apart) instead of the 2n-entry endomorphism table -- the argument of
+// the reference's pippenger_low_memory / pippenger_precomputed (scalar_multiplication.cpp:142-262, :478-574).  Such a table is used once and
+// forgotten (no address-keyed cache: these are test / bench entries of the reference, not the prover's).
+int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12], bool plain = false)
 {
     if (n == 0) {
         host::g1_to_normalised(host::g1_infinity(), out);
@@ -314,10 +336,10 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         return BBGPU_ERR_STATE;
     }
     size_t off = 0;
-    int idx = find_srs(points, n, &off);
+    int idx = plain ? -1 : find_srs(points, n, &off);
     read_host_env();
     if (idx < 0 && n <= (size_t)g_ctx.host_msm_max) { // the verifier's ~20 freshly built points: no allocation, no launch
-        host::g1_to_normalised(host::msm_small(scalars, points, n), out);
+        host::g1_to_normalised(host::msm_small(scalars, points, n, plain ? 8 : 16), out);
         return BBGPU_OK;
     }
     {
@@ -329,10 +351,10 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
     // serve stale points when the caller's vector is freed and its address reused.  Larger unknown tables are taken to be a
     // long-lived SRS and registered on first sight.
     SrsEntry transient{};
-    const bool is_transient = idx < 0 && n < AUTO_REGISTER_MIN_POINTS;
+    const bool is_transient = idx < 0 && (plain || n < AUTO_REGISTER_MIN_POINTS);
     if (idx < 0) {
         uint32_t* d = nullptr;
-        int rc = srs_upload(points, n, &d, g_ctx.stream);
+        int rc = srs_upload(points, n, &d, g_ctx.stream, plain ? 64 : 128);
         if (rc) return rc;
         if (is_transient) {
             transient.host_ptr = points;
@@ -728,6 +750,7 @@ int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n)
     int idx = find_srs(points_endo_table, n, &off);
     if (idx >= 0 && off == 0) {
         g_ctx.srs[idx].auto_registered = false; // the caller now holds the handle: never evicted behind its back
+        g_ctx.srs[idx].handle_exposed = true;
         return idx;
     }
     uint32_t* d = nullptr;
@@ -930,6 +953,12 @@ int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, siz
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     return msm_host_ptrs(scalars, points_endo_table, n, out); // binds the device itself unless the host answers (n = 0, tiny unknown tables)
+}
+
+int bbgpu_msm_g1_plain(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return msm_host_ptrs(scalars, points, n, out, true);
 }
 
 void bbgpu_set_host_thresholds(int msm_max_points, int ntt_max_elements)

@@ -51,7 +51,7 @@ static inline Xyzz g1_madd(const Xyzz& p, const Fq& x, const Fq& y)
 
 // sum_i k_i P_i for a handful of points.  scalars: n x 4 limbs, Montgomery, any representative below 2^256 (the prover hands [0, 2r));
 // points: the 2n-entry endomorphism table (entry 2i = P_i is read, the endo partner is not needed).
-static inline Xyzz msm_small(const uint64_t* scalars, const uint64_t* points_endo, size_t n)
+static inline Xyzz msm_small(const uint64_t* scalars, const uint64_t* points_endo, size_t n, size_t stride = 16 /* u64 words between base points: 16 = the 2n-entry endo table, 8 = a plain n-entry table */)
 {
     constexpr int C = 4, W = 64, NB = 1 << (C - 1); // 64 signed 4-bit windows cover 256 bits; digits in [-8, 8]
     std::vector<int8_t> digit(n * W);
@@ -71,7 +71,7 @@ static inline Xyzz msm_small(const uint64_t* scalars, const uint64_t* points_end
     const Fq zero = { { 0, 0, 0, 0 } };
     for (size_t i = 0; i < n; i++) {
         Fq y;
-        memcpy(y.d, points_endo + 16 * i + 4, 32);
+        memcpy(y.d, points_endo + stride * i + 4, 32);
         neg_y[i] = fq_sub(zero, y);
     }
     Xyzz acc = g1_infinity();
@@ -85,8 +85,8 @@ static inline Xyzz msm_small(const uint64_t* scalars, const uint64_t* points_end
             if (d == 0) continue;
             any = true;
             Fq x, y;
-            memcpy(x.d, points_endo + 16 * i, 32);
-            memcpy(y.d, points_endo + 16 * i + 4, 32);
+            memcpy(x.d, points_endo + stride * i, 32);
+            memcpy(y.d, points_endo + stride * i + 4, 32);
             Xyzz& b = bucket[(d > 0 ? d : -d) - 1];
             b = g1_madd(b, x, d > 0 ? y : neg_y[i]);
         }

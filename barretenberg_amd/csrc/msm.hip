@@ -1711,14 +1711,15 @@ void MsmSlot::release()
 }
 
 // ---- SRS management --------------------------------------------------------------------------------------------------
-int srs_upload(const uint64_t* host_endo_table, size_t n, uint32_t** d_srs_out, hipStream_t st)
+// stride_bytes: 128 = the reference's 2n-entry endomorphism table (base points at the even entries), 64 = a plain n-entry point table
+int srs_upload(const uint64_t* host_table, size_t n, uint32_t** d_srs_out, hipStream_t st, size_t stride_bytes)
 {
     uint32_t* d_tab = nullptr;
     uint32_t* d_srs = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tab, n * 128));
+    HIPCHK(hipMalloc((void**)&d_tab, n * stride_bytes));
     HIPCHK(hipMalloc((void**)&d_srs, n * 64));
-    HIPCHK(hipMemcpyAsync(d_tab, host_endo_table, n * 128, hipMemcpyHostToDevice, st));
-    srs_convert_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_tab, d_srs, (uint32_t)n, 32);
+    HIPCHK(hipMemcpyAsync(d_tab, host_table, n * stride_bytes, hipMemcpyHostToDevice, st));
+    srs_convert_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_tab, d_srs, (uint32_t)n, (uint32_t)(stride_bytes / 4));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipFree(d_tab));

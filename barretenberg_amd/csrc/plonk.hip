@@ -251,28 +251,50 @@ class PlonkProver {
     // without window tables on the SRS, side-by-side single MSMs.  Split in two so that work of the NEXT round which does not depend
     // on this round's challenge can be enqueued on our stream in between: a 2^16-point batch is a ~0.4 ms chain of mostly
     // latency-bound launches on the MSM's own queues, beside which transforms run almost for free.
+    // Tickets that were issued and never waited on would stay `pending` for the life of the process and turn every later host-pointer MSM
+    // into BBGPU_ERR_STATE: whatever happens between commit_begin and commit_end (a failing transform, a failing second ticket), the
+    // destructor drains what is still outstanding.
     struct PendingCommit {
         int count = 0, ticket = -1, tk[3] = { -1, -1, -1 };
         bool batched = true;
         double t0 = 0.0;
+        PendingCommit() = default;
+        PendingCommit(const PendingCommit&) = delete;
+        PendingCommit& operator=(const PendingCommit&) = delete;
+        ~PendingCommit() { drain(); }
+        void drain()
+        {
+            uint64_t sink[4 * 12];
+            if (ticket >= 0) (void)bbgpu_msm_g1_batch_wait(ticket, sink);
+            ticket = -1;
+            for (int& t : tk) {
+                if (t >= 0) (void)bbgpu_msm_g1_wait(t, sink);
+                t = -1;
+            }
+        }
     };
     int commit_begin(const uint64_t* const* scalars, int count, PendingCommit& P)
     {
-        P = PendingCommit();
+        P.drain();
+        P.batched = true;
         P.t0 = now_ms();
         P.count = count;
         // the scalars are produced on `st`; the commitments run on their own queue behind an event (no host round trip)
         HIPCHK(hipEventRecord(scalars_ready, st));
         HIPCHK(hipStreamWaitEvent(st_msm, scalars_ready, 0));
-        P.ticket = bbgpu_msm_g1_device_batch_async(srs, 0, scalars, count, n, st_msm);
-        if (P.ticket >= 0) return BBGPU_OK;
-        if (P.ticket != BBGPU_ERR_ARG) return P.ticket;
+        const int bt = bbgpu_msm_g1_device_batch_async(srs, 0, scalars, count, n, st_msm);
+        if (bt >= 0) {
+            P.ticket = bt;
+            return BBGPU_OK;
+        }
+        if (bt != BBGPU_ERR_ARG) return bt;
         P.batched = false;
         const int W = bbgpu_srs_num_windows(srs, n);
         if (W < 0) return W;
         for (int i = 0; i < count; i++) {
-            P.tk[i] = bbgpu_msm_g1_device_async(srs, 0, scalars[i], n, 0, W, st_msm);
-            if (P.tk[i] < 0) return P.tk[i];
+            const int t = bbgpu_msm_g1_device_async(srs, 0, scalars[i], n, 0, W, st_msm);
+            if (t < 0) return t; // the tickets issued so far are drained by P's destructor
+            P.tk[i] = t;
         }
         return BBGPU_OK;
     }
@@ -280,11 +302,15 @@ class PlonkProver {
     {
         uint64_t res[4 * 12];
         if (P.batched) {
-            RC(bbgpu_msm_g1_batch_wait(P.ticket, res));
+            const int t = P.ticket;
+            P.ticket = -1; // a wait consumes the ticket whatever it returns
+            RC(bbgpu_msm_g1_batch_wait(t, res));
             for (int i = 0; i < P.count; i++) memcpy(out[i], res + 12 * i, 64); // normalised: x, y canonical
         } else {
             for (int i = 0; i < P.count; i++) {
-                RC(bbgpu_msm_g1_wait(P.tk[i], res));
+                const int t = P.tk[i];
+                P.tk[i] = -1;
+                RC(bbgpu_msm_g1_wait(t, res));
                 memcpy(out[i], res, 64);
             }
         }

@@ -79,9 +79,35 @@ void generate_pippenger_point_table(g1::affine_element* points, g1::affine_eleme
     if (rc != BBGPU_OK) die("generate_pippenger_point_table", rc);
 }
 
-// the same sum through the reference's other two (points, scalars, n) entries: pippenger_low_memory (:478-574, which is allowed to
-// clobber `scalars`; this one does not) and alt_pippenger (bench_barretenberg.cpp:487-498)
-g1::element pippenger_low_memory(fr::field_t* scalars, g1::affine_element* points, size_t num_points) { return pippenger(scalars, points, num_points, 0); }
+namespace {
+// sum over a PLAIN n-entry point table (the reference's low-memory / precomputed entries apply beta themselves and never see the 2n-entry
+// endomorphism table): reads exactly num_points * 64 bytes of `points`
+g1::element msm_plain(const char* what, const fr::field_t* scalars, const g1::affine_element* points, size_t num_points)
+{
+    g1::element out;
+    int rc = bbgpu_msm_g1_plain(reinterpret_cast<const uint64_t*>(scalars), reinterpret_cast<const uint64_t*>(points), num_points, reinterpret_cast<uint64_t*>(&out));
+    if (rc != BBGPU_OK) die(what, rc);
+    return out;
+}
+fr::field_t* to_montgomery_copy(const char* what, const fr::field_t* plain, size_t n)
+{
+    using namespace bbgpu::host;
+    fr::field_t* mont = static_cast<fr::field_t*>(aligned_alloc(32, sizeof(fr::field_t) * (n ? n : 1)));
+    if (!mont) die(what, BBGPU_ERR_HIP);
+    for (size_t i = 0; i < n; ++i) {
+        Fr k;
+        memcpy(k.d, plain[i].data, 32);
+        k = fr_to_mont(k);
+        memcpy(mont[i].data, k.d, 32);
+    }
+    return mont;
+}
+} // namespace
+
+// pippenger_low_memory (:142-262): `points` is the PLAIN n-entry table (test_scalar_multiplication.cpp:164-187 allocates n * 64 bytes); the
+// reference is allowed to clobber `scalars` (it leaves the split halves there), this one does not.
+g1::element pippenger_low_memory(fr::field_t* scalars, g1::affine_element* points, size_t num_points) { return msm_plain("pippenger_low_memory", scalars, points, num_points); }
+// alt_pippenger (bench_barretenberg.cpp:487-498): the 2n-entry endomorphism table, like pippenger
 g1::element alt_pippenger(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, size_t forced_bucket_width)
 {
     return pippenger(scalars, points, num_initial_points, forced_bucket_width);
@@ -145,16 +171,8 @@ void compute_wnaf_state(multiplication_runtime_state& state, wnaf_runtime_state&
 g1::element pippenger_internal(fr::field_t* scalars, g1::affine_element* points, size_t num_initial_points, fr::field_t* /*endo_scalars*/,
                                size_t forced_bucket_width)
 {
-    using namespace bbgpu::host;
     if (num_initial_points == 0) return pippenger(scalars, points, 0, forced_bucket_width);
-    fr::field_t* mont = static_cast<fr::field_t*>(aligned_alloc(32, sizeof(fr::field_t) * num_initial_points));
-    if (!mont) die("pippenger_internal (allocation)", BBGPU_ERR_HIP);
-    for (size_t i = 0; i < num_initial_points; ++i) {
-        Fr k;
-        memcpy(k.d, scalars[i].data, 32);
-        k = fr_to_mont(k);
-        memcpy(mont[i].data, k.d, 32);
-    }
+    fr::field_t* mont = to_montgomery_copy("pippenger_internal (allocation)", scalars, num_initial_points);
     g1::element out = pippenger(mont, points, num_initial_points, forced_bucket_width);
     free(mont);
     return out;
@@ -208,15 +226,20 @@ std::vector<g1::affine_element*> generate_pippenger_precompute_table(g1::affine_
     for (size_t i = 0; i + 1 < rounds; ++i) result[rounds - 2 - i] = &table[i * num_points];
     return result;
 }
-// :478-574: the same sum as pippenger() -- the last entry of round_points is the plain point table
+// :478-574: sum_i k_i P_i where round_points[r][j], j < n, are PLAIN n-entry tables (the loop applies beta itself, :520-560) and
+// round_points.back() is the caller's own `points` (test_scalar_multiplication.cpp:226-262 passes them without generate_pippenger_point_table).
+// The internal form takes scalars that have already left Montgomery form (:485-488).
 g1::element pippenger_internal_precomputed(fr::field_t* scalars, const std::vector<g1::affine_element*>& round_points, const size_t num_initial_points,
-                                           fr::field_t* endo_scalars)
+                                           fr::field_t* /*endo_scalars*/)
 {
-    return pippenger_internal(scalars, round_points.back(), num_initial_points, endo_scalars, 0);
+    fr::field_t* mont = to_montgomery_copy("pippenger_internal_precomputed (allocation)", scalars, num_initial_points);
+    g1::element out = msm_plain("pippenger_internal_precomputed", mont, round_points.back(), num_initial_points);
+    free(mont);
+    return out;
 }
 g1::element pippenger_precomputed(fr::field_t* scalars, const std::vector<g1::affine_element*>& round_points, const size_t num_initial_points)
 {
-    return pippenger(scalars, round_points.back(), num_initial_points, 0);
+    return msm_plain("pippenger_precomputed", scalars, round_points.back(), num_initial_points);
 }
 
 } // namespace scalar_multiplication

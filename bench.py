@@ -118,6 +118,26 @@ def limbs_of(v):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
+SKEWED_KINDS = ("all_equal", "zero_one", "small")
+
+
+def skewed_scalars(kind, n):
+    """Scalar vectors (Montgomery form, as the boundary takes them) whose digit distributions are far from uniform -- what real witnesses
+    look like: every scalar equal; scalars in {0, 1, -1}; values below 200.  Pure splitmix64 arithmetic, so the fixtures of
+    tests/golden/msm_r3.json (the reference's results on exactly these vectors, tools/gen_golden_r3.py) need no data beside the seeds."""
+    mont = lambda v: limbs_of(v * (1 << 256) % FR_MODULUS)
+    if kind == "all_equal":
+        k = raw_scalars(1, 0xA11E0A11E0A11E01)[0]
+        return np.tile(mont(sum(int(x) << (64 * i) for i, x in enumerate(k))), (n, 1))
+    if kind == "zero_one":
+        lut = np.stack([mont(0), mont(1), mont(FR_MODULUS - 1)])
+        return lut[(splitmix64(0x0123456789ABCDEF, n) % np.uint64(3)).astype(np.int64)]
+    if kind == "small":
+        lut = np.stack([mont(v) for v in range(200)])
+        return lut[(splitmix64(0x5A11C0DE5A11C0DE, n) % np.uint64(200)).astype(np.int64)]
+    raise ValueError(kind)
+
+
 def to_montgomery_on_device(G, raw, dev):
     """x -> x * 2^256 mod r for a whole vector, on the GPU (one pointwise Montgomery product with 2^512 mod r); returns the device tensor"""
     n = raw.shape[0]

@@ -75,7 +75,10 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
  * it on first sight), so sub-slices `points + 2*off` of a registered table are served from the resident copy
  * (batched_scalar_multiplications slices exactly like that, scalar_multiplication.cpp:720-726). */
 /* The address is only a hint: every address hit is re-validated against a per-point content fingerprint taken at upload (first, last
- * and 14 evenly spaced rows of the range the caller passes; only memory inside that range is read).  A table that was registered on
+ * and 14 evenly spaced rows of the range the caller passes, the spaced rows moving on with every check; only memory inside that range
+ * is read).  RESIDUAL WINDOW: a table rewritten IN PLACE only partially -- first and last row unchanged -- is served from the stale
+ * resident copy until a sampled row falls into the rewritten part (after k checks a rewritten fraction f survives with probability
+ * ~(1 - f)^(14 k)); a caller that edits a slice of a live SRS must release / re-register it.  A table that was registered on
  * first sight and whose memory now holds other points (freed and reused, or refilled in place) is evicted and uploaded again;
  * tables registered on first sight are also evicted least-recently-used beyond BBGPU_SRS_CACHE_BYTES (default 16 GiB of device
  * memory).  A table registered EXPLICITLY keeps its handle until bbgpu_srs_release: mutate it in place only after releasing it
@@ -119,6 +122,12 @@ int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_tab
  * that commits to an all-zero polynomial (zero selector, all-zero witness) therefore hashes differently under the two builds.  Every
  * other result is the unique affine point and is bit-identical. */
 int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12]);
+/* the same sum over a PLAIN table: `points` = n affine points, 64 bytes apart -- the argument convention of the reference's
+ * pippenger_low_memory(scalars, points, num_points) (scalar_multiplication.cpp:142-262, which applies beta itself; its test allocates
+ * exactly n * 64 bytes, test_scalar_multiplication.cpp:164-187) and of round_points.back() in pippenger_precomputed (:478-574,
+ * test_scalar_multiplication.cpp:226-262).  Reads exactly n * 64 bytes of `points`; the table is used once and not cached (these
+ * are the reference's test / bench entries, not the prover's).  scalars not modified. */
+int bbgpu_msm_g1_plain(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12]);
 /* SURVEY 8b "small sizes": the reference's callers include the Verifier's per-proof MSM over ~20 freshly built points
  * (verifier.cpp:359-363) and proofs of n = 4 circuits (test_verifier.cpp:105-122).  Host-pointer MSMs of at most `msm_max_points`
  * points against a table that is not resident, and host-buffer transforms (bbgpu_ntt) of at most `ntt_max_elements` (<= 64)

@@ -327,6 +327,14 @@ class Ref:
         self.lib.ref_pippenger(ptr(scalars), ptr(table), C.c_size_t(n), C.c_size_t(forced_bucket_width), ptr(out))
         return np.array(out)
 
+    def pippenger_low_memory(self, scalars, points, n=None):
+        """the reference's pippenger_low_memory: `points` is the plain n-entry table; `scalars` are clobbered"""
+        n = scalars.shape[0] if n is None else n
+        out = aligned_empty((12,))
+        assert scalars.ctypes.data % 32 == 0 and points.ctypes.data % 32 == 0
+        self.lib.ref_pippenger_low_memory(ptr(scalars), ptr(points), C.c_size_t(n), ptr(out))
+        return np.array(out)
+
     def batched_msm(self, scalars_list, tables_list):
         num = len(scalars_list)
         n = scalars_list[0].shape[0]

@@ -161,6 +161,13 @@ void ref_pippenger(uint64_t* scalars, uint64_t* table, size_t n, size_t forced_b
     ste(out, r);
 }
 
+// scalar_multiplication.cpp:142-262: PLAIN n-entry point table (n * 64 bytes), scalars are clobbered (test_scalar_multiplication.cpp:164-187)
+void ref_pippenger_low_memory(uint64_t* scalars, uint64_t* points, size_t n, uint64_t* out)
+{
+    g1::element r = scalar_multiplication::pippenger_low_memory((fr::field_t*)scalars, (g1::affine_element*)points, n);
+    ste(out, r);
+}
+
 // num jobs over the same n; outputs normalised (scalar_multiplication.cpp:650-772)
 void ref_batched_msm(uint64_t** scalars, uint64_t** tables, size_t n, size_t num, uint64_t* outs)
 {

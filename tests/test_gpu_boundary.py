@@ -94,6 +94,29 @@ def test_srs_cache_lru_under_byte_cap(gpu, oracle, tables):
         assert np.array_equal(gpu.pippenger(sc, b, n)[:8], oracle.msm_affine(sc, t, n)[:8])
 
 
+def test_srs_cache_catches_a_rewritten_middle_slice(gpu, oracle, tables):
+    """ADVICE r2 (low): a table refilled in place only in the MIDDLE (first and last row unchanged) escaped the fixed 16-row sample for ever;
+    the sampled rows now move on with every check, so the stale copy is dropped within a few calls -- and the registry does not grow by one
+    entry per re-registration"""
+    (A, B, C), small, sc = tables
+    n = 2048
+    buf = aligned_empty((2 * n, 8))
+    buf[:] = A
+    want_a = oracle.msm_affine(sc, A, n)
+    assert np.array_equal(gpu.pippenger(sc, buf, n)[:8], want_a[:8])
+    mixed = A.copy()
+    mixed[2 * 300:2 * 1700] = B[2 * 300:2 * 1700]  # 68 % of the rows replaced, both ends kept
+    want_m = oracle.msm_affine(sc, mixed, n)
+    buf[:] = mixed
+    seen = [bool(np.array_equal(gpu.pippenger(sc, buf, n)[:8], want_m[:8])) for _ in range(4)]
+    assert seen[-1] and all(seen[seen.index(True):]), seen  # caught (each check misses with probability 0.32^14), and stays correct afterwards
+    live0 = gpu.srs_cache_stats()[0]
+    for t in (A, mixed, A, mixed, A):                 # five more evict / re-register rounds
+        buf[:] = t
+        gpu.pippenger(sc, buf, n)
+    assert gpu.srs_cache_stats()[0] == live0
+
+
 def test_two_transforms_in_flight_on_two_streams(gpu, oracle):
     """back-to-back transforms on different streams used to share one pass-1 scratch buffer"""
     import torch

@@ -483,6 +483,62 @@ def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
         _check(gpu.g1_sum(np.stack(parts)), case)
 
 
+def test_msm_around_the_table_mode_switch(gpu, oracle, golden):
+    """n = 2^19 - 8, 2^19, 2^19 + 8, 3 * 2^18: both sides of the window-table switch (capi.hip add_srs: 15-bit windows below 2^19, 17-bit
+    from there on) against points the REFERENCE computed for exactly these prefixes (tests/golden/msm_r3.json, tools/gen_golden_r3.py)"""
+    import torch
+    g = golden("msm_r3.json")
+    x = limbs(g["srs_secret_mont"])
+    scalars = oracle.random_scalars(SCALAR_SEED, 3 << 18)
+    d_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
+    for case in g["threshold"]:
+        n = case["n"]
+        h = gpu.srs_generate(x, n)
+        _check(gpu.msm_device(h, d_sc.data_ptr(), n), case)
+        # a prefix of a LARGER table keeps that table's window size: the 2^19 - 8 prefix on 17-bit tables, too
+        if n == (1 << 19) + 8:
+            _check(gpu.msm_device(h, d_sc.data_ptr(), (1 << 19) - 8), [c for c in g["threshold"] if c["n"] == (1 << 19) - 8][0])
+        gpu.srs_release(h)
+
+
+def test_msm_skewed_scalars_full_size(gpu, oracle, golden):
+    """the skewed scalar sets (every scalar equal, {0, 1, -1}, values below 200: bench.skewed_scalars) at the FULL 2^20 size -- the
+    heavy-bucket merge path at the size the headline is quoted on -- against the reference's points for the same vectors"""
+    import torch
+    import bench
+    g = golden("msm_r3.json")
+    n = 1 << 20
+    h = gpu.srs_generate(limbs(g["srs_secret_mont"]), n)
+    for kind in bench.SKEWED_KINDS:
+        case = g["skewed_2e20"][kind]
+        sc = bench.skewed_scalars(kind, n)
+        assert sha(sc) == case["scalars_sha256"], kind
+        d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+        _check(gpu.msm_device(h, d.data_ptr(), n), case)
+        _check(gpu.msm_device(h, d.data_ptr(), 1 << 14), case["first_16384"])
+    gpu.srs_release(h)
+
+
+def test_msm_plain_point_table(gpu, oracle, msm_small, golden):
+    """bbgpu_msm_g1_plain = the reference's pippenger_low_memory convention (scalar_multiplication.cpp:142-262, test_scalar_multiplication.cpp:164-187):
+    a PLAIN n-entry table of exactly n * 64 bytes.  The table ends right at the end of its buffer; result = the reference's own
+    pippenger_low_memory output on the same inputs (= pippenger on the endomorphism table)"""
+    g, srs, table, scalars = msm_small
+    case = golden("msm_r3.json")["low_memory_1000"]
+    n = case["n"]
+    plain = aligned_copy(srs[:n])
+    assert plain.nbytes == n * 64
+    keep = scalars[:n].copy()
+    _check(gpu.pippenger_low_memory(scalars, plain, n), case)
+    assert np.array_equal(scalars[:n], keep)  # the reference may clobber its scalars; this entry does not
+    for m in (1, 7, 24, 25, 999):
+        want = oracle.msm_affine(scalars, table, m)
+        assert np.array_equal(gpu.pippenger_low_memory(scalars, plain, m)[:8], want[:8]), m
+    live0, auto0, _ = gpu.srs_cache_stats()
+    gpu.pippenger_low_memory(scalars, plain, n)
+    assert gpu.srs_cache_stats()[:2] == (live0, auto0)  # used once, never cached
+
+
 def test_msm_row_range_shares_add_up(gpu, oracle, msm_small):
     """bbgpu_msm_g1_device_rows_async: shares of the W * n (window, point) pairs that start and end INSIDE digit windows (what bench.py
     gives N ranks when N does not divide W) add up to the MSM for N = 2, 3, 7, 8 and for ragged cuts; refused without window tables"""
@@ -527,7 +583,7 @@ def test_reference_prover_runs_on_gpu_bit_exact(golden, gates, build):
     exe = os.path.join(root, "oracle", "_ref", build)
     srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
     if not (os.path.exists(exe) and os.path.exists(srs)):
-        pytest.skip("oracle/_ref/%s not built (needs /root/reference at build time)" % build)
+        pytest.fail("oracle/_ref/%s or its transcript is missing: the config-5 checker must travel with the repo (built by __graft_entry__.build() in the build container); a -m gpu run without it has lost its strongest parity evidence" % build)
     env = dict(os.environ, OMP_NUM_THREADS="16")  # the prover's own CPU loops: do not spawn one thread per host core of the box
     r = subprocess.run([exe, "prove", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -549,7 +605,7 @@ def test_reference_prover_other_composers_on_gpu_bit_exact(golden, kind, gates):
     exe = os.path.join(root, "oracle", "_ref", "plonk_gpu_full")
     srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
     if not (os.path.exists(exe) and os.path.exists(srs)):
-        pytest.skip("oracle/_ref/plonk_gpu_full not built (needs /root/reference at build time)")
+        pytest.fail("oracle/_ref/plonk_gpu_full or its transcript is missing: the config-5 checker must travel with the repo (built by __graft_entry__.build() in the build container); a -m gpu run without it has lost its strongest parity evidence")
     env = dict(os.environ, OMP_NUM_THREADS="16", BB_CIRCUIT=kind)
     r = subprocess.run([exe, "prove", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -569,7 +625,7 @@ def test_reference_composer_to_resident_prover_adapter(golden, kind, gates):
     exe = os.path.join(root, "oracle", "_ref", "plonk_gpu")
     srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
     if not (os.path.exists(exe) and os.path.exists(srs)):
-        pytest.skip("oracle/_ref/plonk_gpu not built (needs /root/reference at build time)")
+        pytest.fail("oracle/_ref/plonk_gpu or its transcript is missing: the config-5 checker must travel with the repo (built by __graft_entry__.build() in the build container); a -m gpu run without it has lost its strongest parity evidence")
     env = dict(os.environ, OMP_NUM_THREADS="16")
     if kind != "standard":
         env["BB_CIRCUIT"] = kind

@@ -169,14 +169,14 @@ def test_shim_host_members_match_oracle(oracle):
         subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shim_host.cpp"), "-L" + pkg, "-lbbshim", "-lbbgpu",
                         "-Wl,-rpath," + pkg], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0")).stdout
-    assert "pipint ok" in out and "pippre ok" in out
+    assert "pipint ok" in out and "pippre ok" in out and "piplow ok" in out
     vec, width, raw = {}, {}, {}
     for line in out.splitlines():
         t = line.split()
         if t[0] == "width":
             width[int(t[1])] = int(t[2])
-        elif t[0] == "pipint" or t[0] == "pippre":
-            assert t[1] == "ok", "pippenger_internal / alt_pippenger_internal differ from pippenger() or from (sum k_i i) G"
+        elif t[0] in ("pipint", "pippre", "piplow"):
+            assert t[1] == "ok", "pippenger_internal / alt_pippenger_internal / the plain-table entries differ from pippenger() or from (sum k_i i) G"
         elif t[0] in ("pre", "base", "prerounds"):
             raw.setdefault(t[0], []).append(t[1:])
         elif t[0].startswith(("wnaf", "skew", "state", "iter")):

@@ -4,7 +4,7 @@ reference itself (tools/gen_golden.py -> oracle/_ref), (3) property checks from 
 import numpy as np
 import pytest
 
-from oracle.pyoracle import FQ, FR, FR_MODULUS, NTT_KINDS, from_int, to_int
+from oracle.pyoracle import FQ, FR, FR_MODULUS, NTT_KINDS, aligned_copy, from_int, to_int
 from tests.util import CONST_SEED, NTT_SEED, SCALAR_SEED, SRS_SEED, limbs, noncanonical, sha
 
 F = {"fq": FQ, "fr": FR}
@@ -325,3 +325,24 @@ def test_poly_oracle_internal_consistency(oracle):
     w = P.root(5)
     assert P.plain(P.permutation_lagrange_base(ident, n)) == [pow(w, i, FR_MODULUS) for i in range(n)]
     assert P.plain(P.permutation_lagrange_base(ident + np.uint32(1 << 31), n)) == [7 * pow(w, i, FR_MODULUS) % FR_MODULUS for i in range(n)]
+
+
+def test_oracle_on_skewed_scalars_and_plain_tables(oracle, golden):
+    """round-3 fixtures (tests/golden/msm_r3.json, outputs of the reference: tools/gen_golden_r3.py): bench.skewed_scalars reproduces the vectors
+    the reference was run on (SHA-256), and the restatement gives the reference's points for their 2^14-point prefixes and for the
+    pippenger_low_memory case (scalar_multiplication.cpp:142-262: same sum as pippenger on the endomorphism table)"""
+    import bench
+    from tests.util import SCALAR_SEED, limbs, sha
+    g = golden("msm_r3.json")
+    m = 1 << 14
+    srs = oracle.make_srs(limbs(g["srs_secret_mont"]), m)
+    table = oracle.point_table(srs)
+    for kind in bench.SKEWED_KINDS:
+        case = g["skewed_2e20"][kind]
+        sc = bench.skewed_scalars(kind, 1 << 20)
+        assert sha(sc) == case["scalars_sha256"], kind
+        got = oracle.msm_affine(aligned_copy(sc[:m]), table, m)
+        assert np.array_equal(got[0:4], limbs(case["first_16384"]["x"])) and np.array_equal(got[4:8], limbs(case["first_16384"]["y"])), kind
+    case = g["low_memory_1000"]
+    got = oracle.msm_affine(oracle.random_scalars(SCALAR_SEED, case["n"]), table, case["n"])
+    assert np.array_equal(got[0:4], limbs(case["x"])) and np.array_equal(got[4:8], limbs(case["y"]))
