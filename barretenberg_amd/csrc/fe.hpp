@@ -57,6 +57,14 @@ template <class F, int L, int V> struct Fe {
 template <class F> using FeT = Fe<F, 1, 1>;   // canonical constant
 template <class F> using FeN = Fe<F, 1, 12>;  // the storage type of kernels: tight limbs, value < 12p
 
+// The same with EXACT limbs: d[0..7] < 2^29 (what carry_full delivers; L = 1 only promises < 2^29 + 8).  Subtracting such a value
+// needs a borrow-proofing offset of one 2^29 instead of two, which keeps the difference one unit tighter: sub(a, FeE) has
+// L = L1 + 2.  That unit decides whether Y3 = R (Q - X3) - Y1 PPP of the mixed addition fits one shared reduction without
+// renormalising -Y1 first (g1.hpp madd_ip).
+template <class F, int V> struct FeE : Fe<F, 1, V> {
+    BB_HD FeE() {}
+};
+
 // ---- constants --------------------------------------------------------------------------------------------------
 struct Limbs9 {
     uint32_t d[NL];
@@ -121,6 +129,16 @@ BB_HD Fe<F, L1 + L2 + 2, V1 + V2 + 1> sub(const Fe<F, L1, V1>& a, const Fe<F, L2
     for (int i = 0; i < NL; i++) r.d[i] = a.d[i] + c.d[i] - b.d[i];
     return r;
 }
+// the same for a subtrahend with exact limbs: offset 2^29 per limb, result < L1*U + 2*2^29
+template <class F, int L1, int V1, int V2>
+BB_HD Fe<F, L1 + 2, V1 + V2 + 1> sub(const Fe<F, L1, V1>& a, const FeE<F, V2>& b)
+{
+    constexpr Limbs9 c = make_sub_const<F>(0, V2 + 1);
+    Fe<F, L1 + 2, V1 + V2 + 1> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.d[i] = a.d[i] + c.d[i] - b.d[i];
+    return r;
+}
 // -a + (V+1)p
 template <class F, int L1, int V1> BB_HD Fe<F, L1 + 2, V1 + 1> neg(const Fe<F, L1, V1>& a)
 {
@@ -147,9 +165,9 @@ template <class F, int V> BB_HD Fe<F, 1, V> weak(const Fe<F, 1, V>& a)
 }
 
 // full sequential carry: limbs 0..7 exactly < 2^29 (unique representation of the integer value)
-template <class F, int L, int V> BB_HD Fe<F, 1, V> carry_full(const Fe<F, L, V>& a)
+template <class F, int L, int V> BB_HD FeE<F, V> carry_full(const Fe<F, L, V>& a)
 {
-    Fe<F, 1, V> r;
+    FeE<F, V> r;
     uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < NL - 1; i++) {
@@ -290,6 +308,33 @@ BB_HD void mul2_raw(const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint
     out[NL - 1] = (uint32_t)acc;
 }
 
+// In-place forms: a <- a*b, c <- a*b + c*d.  On the device the result takes the REGISTERS of the replaced operand (fe_mont_gfx950.h:
+// operand limb j is last read in column j + 8, result limb j is written after column j + 9), so a loop-carried value that is
+// multiplied in place needs no copy on the loop's back edge; elsewhere they are the plain products.
+template <class F> BB_HD void mul_raw_inplace(uint32_t (&a)[NL], const uint32_t (&b)[NL])
+{
+#if BBGPU_MONT_ASM
+    mul_raw_inplace_gfx950<F>(a, b);
+    return;
+#endif
+    uint32_t t[NL];
+    mul_raw<F>(a, b, t);
+#pragma unroll
+    for (int i = 0; i < NL; i++) a[i] = t[i];
+}
+template <class F>
+BB_HD void mul2_raw_inplace(const uint32_t (&a)[NL], const uint32_t (&b)[NL], uint32_t (&c)[NL], const uint32_t (&d)[NL])
+{
+#if BBGPU_MONT_ASM
+    mul2_raw_inplace_gfx950<F>(a, b, c, d);
+    return;
+#endif
+    uint32_t t[NL];
+    mul2_raw<F>(a, b, c, d, t);
+#pragma unroll
+    for (int i = 0; i < NL; i++) c[i] = t[i];
+}
+
 constexpr int mul_v(int v1, int v2)
 {
     return (v1 * v2) / 169 + 2;
@@ -335,6 +380,31 @@ template <class F, int L1, int V1, int L2, int V2, int L3, int V3, int L4, int V
 BB_HD auto mul_sub(const Fe<F, L1, V1>& a, const Fe<F, L2, V2>& b, const Fe<F, L3, V3>& c, const Fe<F, L4, V4>& d)
 {
     return mul_add(a, b, weak(neg(c)), d);
+}
+
+// a*b with the result in a's registers (use where a dies here); no automatic renormalisation: the caller's bounds must fit
+template <class F, int L1, int V1, int L2, int V2>
+BB_HD Fe<F, 1, mul_v(V1, V2)> mul_ip(const Fe<F, L1, V1>& a, const Fe<F, L2, V2>& b)
+{
+    static_assert(L1 * L2 <= 6, "limb bounds too large: weak() an operand");
+    static_assert(mul_v(V1, V2) <= MAXV, "product value bound too large");
+    Fe<F, 1, mul_v(V1, V2)> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.d[i] = a.d[i];
+    mul_raw_inplace<F>(r.d, b.d);
+    return r;
+}
+// a*b + c*d with the result in c's registers (one reduction)
+template <class F, int L1, int V1, int L2, int V2, int L3, int V3, int L4, int V4>
+BB_HD Fe<F, 1, mul2_v(V1, V2, V3, V4)> mul_add_ip(const Fe<F, L1, V1>& a, const Fe<F, L2, V2>& b, const Fe<F, L3, V3>& c, const Fe<F, L4, V4>& d)
+{
+    static_assert(L1 * L2 + L3 * L4 <= 6, "limb bounds too large for a shared reduction: weak() an operand");
+    static_assert(mul2_v(V1, V2, V3, V4) <= MAXV, "value bound too large");
+    Fe<F, 1, mul2_v(V1, V2, V3, V4)> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.d[i] = c.d[i];
+    mul2_raw_inplace<F>(a.d, b.d, r.d, d.d);
+    return r;
 }
 
 template <class F, int L1, int V1> BB_HD Fe<F, 1, mul_v(V1, V1)> sqr(const Fe<F, L1, V1>& a)

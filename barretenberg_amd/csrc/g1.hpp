@@ -116,41 +116,57 @@ template <int V> BB_HD void madd(Xyzz& acc, const AffineV<V>& a)
     acc.zzz = ZZZ3;
 }
 
-// The same for the bucket accumulation's hot loop, where the two rare tests are the only non-arithmetic work per addition: the
-// accumulator's infinity is carried as a flag (set at a bucket start and by P + (-P)) instead of nine ORs over zz, and the full
-// "PP == 0 (mod p)" comparison (27 compares over the limbs) runs only when limb 0 of PP is one of the three values it can have then.
-template <int V> BB_HD void madd_flagged(Xyzz& acc, bool& acc_inf, const AffineV<V>& a)
+// The same for the bucket accumulation's hot loop (msm_accumulate_kernel), written around what that loop pays for besides its ten
+// products (round 3; the instruction counts are those of the gfx950 ISA):
+//  * the accumulator's infinity is a FLAG (set at a bucket start and by P + (-P)); the caller takes the `acc = a` branch itself, so
+//    this function only sees a finite accumulator -- and sets the flag (and a clean infinity) when the sum cancels;
+//  * the results land in the accumulator's own registers: ZZ3, ZZZ3 and Y3 are in-place products (mul_ip / mul_add_ip, the result
+//    takes the registers of the operand it replaces), X3 is plain limb arithmetic the register allocator coalesces -- so the loop's
+//    back edge carries no copies (round 2: 36 v_mov per addition);
+//  * X3 is carried out EXACTLY (carry_full, 27 dependent instructions instead of weak()'s 24): with an exact subtrahend Q - X3 has
+//    L = 3 and R (Q - X3) + (-Y1) PPP fits the shared reduction with -Y1 left at L = 3, i.e. without the 24-instruction
+//    renormalisation of -Y1 the bound L1 L2 + L3 L4 <= 6 used to demand;
+//  * the full "PP == 0 (mod p)" comparison (27 compares over the limbs) runs only when limb 0 of PP is one of the three values it
+//    can have then; P == acc (rare: equal points in one bucket) doubles the accumulator itself, so the operand is dead after the
+//    first two products and they, too, run in place.
+// a.x, a.y: the operand (y already negated where the digit is negative), consumed.
+template <int VX, int VY> BB_HD void madd_ip(Xyzz& acc, bool& acc_inf, const Fe<Fq, 1, VX>& ax, const Fe<Fq, 1, VY>& ay)
 {
-    if (acc_inf) {
-        from_affine(acc, a);
-        acc_inf = false;
-        return;
-    }
-    auto U2 = mul(a.x, acc.zz);
-    auto S2 = mul(a.y, acc.zzz);
+    auto U2 = mul_ip(ax, acc.zz);
+    auto S2 = mul_ip(ay, acc.zzz);
     auto P = weak(sub(U2, acc.x));
     auto R = weak(sub(S2, acc.y));
     auto PP = sqr(P);
     constexpr Limbs9 p2 = make_multiple<Fq>(2);
-    if ((PP.d[0] == 0 || PP.d[0] == Fq::P[0] || PP.d[0] == p2.d[0]) && is_zero_mulout(PP)) { // same x: rare
+    const bool same_x = (PP.d[0] == 0 || PP.d[0] == Fq::P[0] || PP.d[0] == p2.d[0]) && is_zero_mulout(PP); // rare
+    // Two one-sided branches instead of if / else: each updates the accumulator's registers in place under its own lane mask.
+    // An if / else is a two-way merge of the accumulator, which the compiler resolves with a second register set and 36 copies per
+    // trip; the empty asm statement keeps it from folding the two back into one.
+    if (same_x) {
         if (is_zero_slow(R)) {
-            dbl_affine(acc, a);
+            Xyzz d;
+            dbl(d, acc);
+            acc = d;
         } else {
             set_infinity(acc);
             acc_inf = true;
         }
-        return;
     }
-    auto PPP = mul(P, PP);
-    auto Q = mul(acc.x, PP);
-    auto X3 = weak(sub(sqr(R), add(PPP, dbl(Q))));
-    auto Y3 = mul_sub(R, sub(Q, X3), acc.y, PPP);
-    auto ZZ3 = mul(acc.zz, PP);
-    auto ZZZ3 = mul(acc.zzz, PPP);
-    acc.x = X3;
-    acc.y = Y3;
-    acc.zz = ZZ3;
-    acc.zzz = ZZZ3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");
+#endif
+    if (!same_x) {
+        auto ZZ3 = mul_ip(acc.zz, PP);
+        auto PPP = mul_ip(P, PP);
+        auto Q = mul_ip(PP, acc.x);
+        auto X3 = carry_full(sub(sqr(R), add(PPP, dbl(Q))));
+        auto ZZZ3 = mul_ip(acc.zzz, PPP);
+        auto Y3 = mul_add_ip(R, sub(Q, X3), neg(acc.y), PPP);
+        acc.x = X3;
+        acc.y = Y3;
+        acc.zz = ZZ3;
+        acc.zzz = ZZZ3;
+    }
 }
 
 // r = p + q   [add-2008-s], 12M + 2S, all exceptional cases
@@ -230,6 +246,30 @@ BB_HD void load_affine_m261(AffineV<1>& r, const uint32_t* w16)
     for (int i = 0; i < NL; i++) {  // stored canonical by construction (store_affine_m261): value < p
         r.x.d[i] = ux.d[i];
         r.y.d[i] = uy.d[i];
+    }
+}
+// The same with y -> p - y where `negy` (a negative digit), done on the PACKED words: one 8-word borrow chain and 8 selects, after
+// which the ordinary unpack delivers exact limbs again.  (Negating the unpacked limbs costs as much -- 9 subtractions, 9 selects --
+// and leaves y at L = 3, which the accumulator's y must not have: madd_ip relies on L = 1 there.)  y != 0 on this curve, so
+// p - y is canonical; the type still says < 2p.
+BB_HD void load_affine_m261_signed(Fe<Fq, 1, 1>& x, Fe<Fq, 1, 2>& y, const uint32_t (&w16)[16], bool negy)
+{
+    uint32_t wx[8], wy[8];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        wx[i] = w16[i];
+        const uint32_t pi = (uint32_t)(Fq::P64[i >> 1] >> ((i & 1) * 32));
+        const uint32_t yi = w16[8 + i];
+        const uint32_t d = pi - yi, d2 = d - borrow;
+        borrow = (uint32_t)(pi < yi) | (uint32_t)(d < borrow);
+        wy[i] = negy ? d2 : yi;
+    }
+    Fe<Fq, 1, 6> ux = unpack<Fq>(wx), uy = unpack<Fq>(wy);
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        x.d[i] = ux.d[i];
+        y.d[i] = uy.d[i];
     }
 }
 BB_HD void store_affine_m261(uint32_t* w16, const Fe<Fq, 1, 12>& x, const Fe<Fq, 1, 12>& y)

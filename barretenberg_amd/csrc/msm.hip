@@ -459,7 +459,8 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
             run += totals[w];
         }
         bases[nw] = run;
-        *gstart_end = run;
+        gstart_end[0] = run;
+        gstart_end[1] = 0xffffffffu; // sentinel: the accumulation's last lane walks past the last bucket into a dummy one (msm_accumulate_kernel)
     }
 }
 
@@ -815,33 +816,72 @@ __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kerne
     uint32_t next_end = gstart[b + 1];
     Xyzz acc;
     set_infinity(acc);
-    bool acc_inf = true; // the accumulator's infinity as a flag (madd_flagged)
-    // software pipeline: the gather of entry e+1 (index, then 64 bytes of point, possibly from HBM when the window
-    // tables exceed the Infinity Cache) is in flight while the ~2,200 VALU instructions of the mixed addition of entry e run
-    // The INDEX runs two entries ahead: the gather address of entry e+1 is then known when iteration e starts, instead of costing an
-    // index-load latency before the gather can even be issued.
+    uint32_t after_next = gstart[min(b + 2, total_buckets + 1)]; // one boundary ahead, so that a flush does not wait for its load
+    bool acc_inf = true; // the accumulator is the point at infinity (as a flag): at the start of the chunk and after P + (-P)
+    // Software pipeline (round 3 shape).  Three things are in flight while the ~2,100 VALU instructions of one mixed addition run:
+    // the 64-byte table row of entry e+1 (gather from HBM: the window tables exceed the Infinity Cache), the sorted-list word of
+    // entry e+2 (so that the next gather's address is known when it is issued), and the bucket boundary after the next.  The row
+    // is unpacked into the operand registers at the END of the iteration (its load has had the whole addition to land) and the
+    // next gather is issued into the registers that frees -- no second row buffer and no register-to-register copy of the row
+    // (round 2 copied 16 words per addition); the operand itself dies in the addition's first two products.
     uint32_t v = sorted[p0];
-    uint32_t vn = sorted[min(p0 + 1, p1 - 1)];
+    uint32_t vn = sorted[p0 + 1 < p1 ? p0 + 1 : p0];
     uint32_t w[16];
     ld16(srs + (size_t)(v & 0x7fffffffu) * 16, w);
-    for (uint32_t e = p0; e < p1; e++) {
+    Fe<Fq, 1, 1> px;
+    Fe<Fq, 1, 2> py;
+    load_affine_m261_signed(px, py, w, (v >> 31) != 0);
+    ld16(srs + (size_t)(vn & 0x7fffffffu) * 16, w);
+    // Every lane runs exactly `ch` trips -- a wave-uniform count: with a per-lane exit the compiler keeps the live-out values of
+    // the lanes that left in a second set of registers (38 copies per trip), and a per-lane "still has entries" predicate around
+    // the addition costs 40 more registers (190: two waves per SIMD).  Only the ONE lane of the grid that holds the end of the
+    // list has fewer entries: at e == M it flushes its last bucket like any other and walks on into a DUMMY bucket (index
+    // total_buckets; gstart[total_buckets + 1] is a sentinel no entry reaches, written by sort_bases_kernel), where its remaining
+    // trips re-add its last point to a sum nobody reads (slot total_buckets + t lies inside the partials array: MsmCarve keeps one
+    // chunk more than any grid has; the merge kernels stop at total_buckets).
+    uint32_t e = p0;
+    uint32_t trips = ch; // ch >= 1; a scalar count tested at the bottom: the values the final store reads are then the loop's own registers
+    do {
         const uint32_t vnn = sorted[min(e + 2, p1 - 1)];
-        uint32_t wn[16];
-        ld16(srs + (size_t)(vn & 0x7fffffffu) * 16, wn);
-        if (e == next_end) {
-            store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
-            set_infinity(acc);
-            acc_inf = true;
-            do { b++; next_end = gstart[b + 1]; } while (next_end <= e); // skip empty buckets
+        // One-sided branches only (see madd_ip): a lane either starts a bucket with this entry -- after flushing the finished
+        // bucket's partial, or because its previous sum cancelled to infinity -- or adds the entry to its accumulator.
+        const bool start = (e == next_end) || acc_inf;
+        if (start) {
+            if (e == next_end) {
+                // acc is a valid point here whatever the flag says (P + (-P) leaves a clean infinity behind)
+                store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
+                b++;
+                next_end = after_next;
+                while (next_end <= e) { b++; next_end = gstart[b + 1]; } // skip empty buckets (rare at the sizes that matter)
+                after_next = gstart[min(b + 2, total_buckets + 1)];
+            }
+            acc.x = px;
+            acc.y = py;
+            acc.zz = fe_one<Fq>();
+            acc.zzz = fe_one<Fq>();
+            acc_inf = false;
         }
-        AffineV<1> p;
-        load_affine_m261(p, w);
-        madd_flagged(acc, acc_inf, cond_neg_affine(p, (v >> 31) != 0));
-        v = vn;
-        vn = vnn;
+        asm volatile("" ::: "memory");
+        if (!start) madd_ip(acc, acc_inf, px, py);
+#ifdef BBGPU_ACC_JUNK // issue-model experiment: extra cheap VALU instructions per trip, results unused
+        {
+            uint32_t j0 = e, j1 = vn;
 #pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = wn[i];
-    }
+            for (int q = 0; q < BBGPU_ACC_JUNK / 2; q++) asm volatile("v_and_b32 %0, 0x1fffffff, %1\n\tv_add_u32 %1, %0, %1" : "+v"(j0), "+v"(j1));
+        }
+#endif
+#ifdef BBGPU_ACC_JUNKMAD // the same with dependent v_mad_u64_u32
+        {
+            unsigned long long ja = e;
+#pragma unroll
+            for (int q = 0; q < BBGPU_ACC_JUNKMAD; q++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(ja) : "v"(vn) : "vcc");
+        }
+#endif
+        load_affine_m261_signed(px, py, w, (vn >> 31) != 0);
+        ld16(srs + (size_t)(vnn & 0x7fffffffu) * 16, w);
+        vn = vnn;
+        e++;
+    } while (--trips != 0);
     store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
 }
 
@@ -1356,7 +1396,7 @@ static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
     L.binstart = p;    p += al(nw * 1024 * 4 + 256);
     L.bintot = p;      p += al(nw * 1024 * 4 + 256);
     L.tmp_entries = p; p += al(nw * n * 4);                      // pass-A output
-    L.gstart = p;      p += al((nw * P.nb + 1) * 4);
+    L.gstart = p;      p += al((nw * P.nb + 2) * 4);             // + M at [total_buckets] + a sentinel behind it
     L.totals = p;      p += al(nw * 8 + 512);                    // totals, bases (nw + 1)
     L.heavy = p;       p += al((nw * P.nb + 1) * 4);             // heavy-bucket queue
     L.sorted = p;      p += al(nw * n * 4);

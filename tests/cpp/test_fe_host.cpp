@@ -151,6 +151,33 @@ static void test_group()
       dbl(s3, inf); CHECK(is_infinity(s3), "dbl inf");
       // xyzz store/load roundtrip
       uint32_t w[32]; store_xyzz(w, acc); Xyzz l; load_xyzz(l, w); xyzz_to_ref_affine(l, got); CHECK(!memcmp(got, g2, 96), "xyzz store/load"); }
+    // the accumulation's hot-loop form: rows in the device format (packed Montgomery-261), sign applied on the packed words
+    // (load_affine_m261_signed), flagged in-place addition (madd_ip) -- the same chain as above plus P + P, P - P and a restart
+    { Xyzz hacc; set_infinity(hacc); bool hinf = true;
+      uint64_t hr[12]; memset(hr, 0, 96); hr[7] = 1ULL << 63;
+      auto step = [&](int i, bool negf) {
+          AffineV<2> a; load_ref_affine(a, &srs[8 * i]); uint32_t w[16]; store_affine_m261(w, a.x, a.y);
+          Fe<Fq, 1, 1> px; Fe<Fq, 1, 2> py; load_affine_m261_signed(px, py, w, negf);
+          for (int l = 0; l < NL - 1; l++) CHECK(px.d[l] < (1u << 29) && py.d[l] < (1u << 29), "signed loader: exact limbs");
+          if (hinf) { hacc.x = px; hacc.y = py; hacc.zz = fe_one<Fq>(); hacc.zzz = fe_one<Fq>(); hinf = false; }
+          else madd_ip(hacc, hinf, px, py);
+          uint64_t pt[8]; memcpy(pt, &srs[8 * i], 64); if (negf) orc_neg(ORC_FQ, pt + 4, pt + 4);
+          orc_g1_mixed_add(hr, pt, hr);
+          ref_norm(hr, want);
+          if (hinf) { CHECK(is_infinity(hacc), "madd_ip leaves a clean infinity"); CHECK((want[7] >> 63) != 0, "madd_ip infinity flag"); }
+          else { xyzz_to_ref_affine(hacc, got); CHECK(!memcmp(got, want, 96), "madd_ip chain"); }
+          for (int l = 0; l < NL - 1; l++) CHECK(hacc.x.d[l] < (1u << 29) + 8 && hacc.y.d[l] < (1u << 29) + 8 && hacc.zz.d[l] < (1u << 29) + 8 && hacc.zzz.d[l] < (1u << 29) + 8, "madd_ip limb bounds");
+      };
+      for (int i = 0; i < N; i++) step(i, (i % 3) == 1);
+      step(5, false); step(5, false);                 // ... + P + P: the second hits acc == operand only by accident; force it:
+      set_infinity(hacc); hinf = true; memset(hr, 0, 96); hr[7] = 1ULL << 63;
+      step(7, false); step(7, false);                 // P + P -> doubling branch
+      step(9, true);
+      set_infinity(hacc); hinf = true; memset(hr, 0, 96); hr[7] = 1ULL << 63;
+      step(11, true); step(11, false);                // -P + P -> infinity, flag set
+      CHECK(hinf, "madd_ip P + (-P) sets the flag");
+      step(12, false); step(13, true);                // restart from the flag
+    }
     printf("group ok (fails so far %d)\n", fails);
 }
 

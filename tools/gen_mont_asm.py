@@ -26,44 +26,52 @@ def mad(x, y, first):
     return f"v_mad_u64_u32 {ACC}, vcc, {x}, {y}, {'0' if first else ACC}"
 
 
-def low_column(ins, k, prods):
+# Register roles.  Default ("r"): the nine outputs double as the quotient digits m[0..8] -- m[j] is dead from column j + 9 on, which is
+# when out[j] is written.  In-place forms (q = "m", o = the consumed operand): the result takes the registers of one OPERAND instead
+# (operand limb j is last read in column j + 8, out[j] is written at the end of column j + 9) and the quotient digits live in nine
+# scratch registers.  Same instructions, same count; what changes is where the result lands: a loop-carried value multiplied in place
+# (ZZ3 = ZZ1 * PP in the bucket accumulation) stays in its registers and the loop's back edge needs no copies.
+def low_column(ins, k, prods, q="r"):
     """prods: list of (x, y) operand names of the a*b-type products of column k"""
     first = (k == 0)
     for (x, y) in prods:
         ins.append(mad(x, y, first))
         first = False
     for i in range(k):
-        ins.append(mad(f"%[r{i}]", f"%[p{k - i}]", False))
+        ins.append(mad(f"%[{q}{i}]", f"%[p{k - i}]", False))
     ins.append(f"v_mul_lo_u32 {TMP}, {ACC_LO}, %[pinv]")
-    ins.append(f"v_and_b32 %[r{k}], {MASK}, {TMP}")
-    ins.append(mad(f"%[r{k}]", "%[p0]", False))
+    ins.append(f"v_and_b32 %[{q}{k}], {MASK}, {TMP}")
+    ins.append(mad(f"%[{q}{k}]", "%[p0]", False))
     ins.append(f"v_lshrrev_b64 {ACC}, 29, {ACC}")
 
 
-def high_column(ins, k, prods):
+def high_column(ins, k, prods, q="r", o="r"):
     for (x, y) in prods:
         ins.append(mad(x, y, False))
     for i in range(k - (NL - 1), NL):
-        ins.append(mad(f"%[r{i}]", f"%[p{k - i}]", False))
+        ins.append(mad(f"%[{q}{i}]", f"%[p{k - i}]", False))
     # r[k-9] is dead as a Montgomery quotient digit from column k-1 on (m[i] is last used in column i+8)
     if k < 2 * NL - 2:
-        ins.append(f"v_and_b32 %[r{k - NL}], {MASK}, {ACC_LO}")
+        ins.append(f"v_and_b32 %[{o}{k - NL}], {MASK}, {ACC_LO}")
         ins.append(f"v_lshrrev_b64 {ACC}, 29, {ACC}")
     else:
-        # last column: limb 7 and the (unmasked) top limb; r8 = m[8] was an operand of this column's last mad
-        ins.append(f"v_and_b32 %[r7], {MASK}, {ACC_LO}")
-        ins.append(f"v_alignbit_b32 %[r8], {ACC_HI}, {ACC_LO}, 29")
+        # last column: limb 7 and the (unmasked) top limb; r8 = m[8] (or the operand's limb 8) was an operand of this column's mads
+        ins.append(f"v_and_b32 %[{o}7], {MASK}, {ACC_LO}")
+        ins.append(f"v_alignbit_b32 %[{o}8], {ACC_HI}, {ACC_LO}, 29")
 
 
-def gen_mul():
+def gen_mul(q="r", o="r"):
     ins = []
     for k in range(2 * NL - 1):
         prods = [(f"%[a{i}]", f"%[b{k - i}]") for i in range(NL) if 0 <= k - i < NL]
-        (low_column if k < NL else high_column)(ins, k, prods)
+        if k < NL:
+            low_column(ins, k, prods, q)
+        else:
+            high_column(ins, k, prods, q, o)
     return ins
 
 
-def gen_mul2():
+def gen_mul2(q="r", o="r"):
     ins = []
     for k in range(2 * NL - 1):
         prods = []
@@ -71,7 +79,10 @@ def gen_mul2():
             if 0 <= k - i < NL:
                 prods.append((f"%[a{i}]", f"%[b{k - i}]"))
                 prods.append((f"%[c{i}]", f"%[d{k - i}]"))
-        (low_column if k < NL else high_column)(ins, k, prods)
+        if k < NL:
+            low_column(ins, k, prods, q)
+        else:
+            high_column(ins, k, prods, q, o)
     return ins
 
 
@@ -135,6 +146,16 @@ def main():
     print()
     print(emit_fn("mul2_raw_gfx950", "const uint32_t (&a)[9], const uint32_t (&b)[9], const uint32_t (&c)[9], const uint32_t (&d)[9], uint32_t (&out)[9]",
                   gen_mul2(), outs, a_in + b_in + c_in + d_in, []))
+    print()
+    # in-place forms: the result replaces operand a (mul) / operand c (a*b + c*d); quotient digits in scratch registers
+    m_tmp = [f"m{i}" for i in range(NL)]
+    m_out = [f'[m{i}] "=&v"(m{i})' for i in range(NL)]
+    a_io = [f'[a{i}] "+v"(a[{i}])' for i in range(NL)]
+    c_io = [f'[c{i}] "+v"(c[{i}])' for i in range(NL)]
+    print(emit_fn("mul_raw_inplace_gfx950", "uint32_t (&a)[9], const uint32_t (&b)[9]", gen_mul("m", "a"), a_io + m_out, b_in, m_tmp))
+    print()
+    print(emit_fn("mul2_raw_inplace_gfx950", "const uint32_t (&a)[9], const uint32_t (&b)[9], uint32_t (&c)[9], const uint32_t (&d)[9]",
+                  gen_mul2("m", "c"), c_io + m_out, a_in + b_in + d_in, m_tmp))
     print("} // namespace bbgpu")
 
 
