@@ -763,6 +763,17 @@ template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_staged_k
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void store_raw(uint32_t* dst, const Xyzz& p)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BBGPU_STORE_RAW_X4)
+    // 8-byte stores off one base address.  The compiler's own choice -- nine 16-byte stores -- wants quadruples of adjacent registers,
+    // and the accumulator's limbs sit wherever the in-place products of the hot loop leave them: it then shuffles 8 limbs out and
+    // back on EVERY trip (22 v_mov + 11 v_mov_b64 in the hot path); pairs it manages to keep adjacent (6 copies left, in the latch).
+    uint32_t v[4 * NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) { v[i] = p.x.d[i]; v[NL + i] = p.y.d[i]; v[2 * NL + i] = p.zz.d[i]; v[3 * NL + i] = p.zzz.d[i]; }
+#pragma unroll
+    for (int i = 0; i < 4 * NL; i += 2)
+        asm volatile("global_store_dwordx2 %0, %1, off offset:%2" :: "v"(dst), "v"(((unsigned long long)v[i + 1] << 32) | v[i]), "n"(4 * i) : "memory");
+#else
 #pragma unroll
     for (int i = 0; i < NL; i++) {
         dst[i] = p.x.d[i];
@@ -770,6 +781,7 @@ __device__ __forceinline__ void store_raw(uint32_t* dst, const Xyzz& p)
         dst[2 * NL + i] = p.zz.d[i];
         dst[3 * NL + i] = p.zzz.d[i];
     }
+#endif
 }
 __device__ __forceinline__ void load_raw(Xyzz& p, const uint32_t* src)
 {
