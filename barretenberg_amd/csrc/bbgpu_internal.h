@@ -56,6 +56,11 @@ int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_table, size_t n, uint32_t** d_srs_out, hipStream_t st, size_t stride_bytes = 128);
 int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);
 
+// capi.hip: the caller's host buffers cross the link through the library's OWN pinned buffers (see host_to_device)
+int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
+int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st);
+void host_stage_release();
+
 // plonk.hip
 void plonk_release_all();
 

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 #include "bbgpu_internal.h"
@@ -93,6 +94,12 @@ struct Context {
     uint64_t* d_poly_tmp = nullptr;
     size_t poly_tmp_cap = 0;
     MsmTiming last;
+    // pinned staging for the callers' host buffers (host_to_device / device_to_host_sync)
+    static constexpr size_t HOST_CHUNK = (size_t)4 << 20;
+    void* h_stage[2] = { nullptr, nullptr };
+    hipEvent_t h_stage_free[2] = { nullptr, nullptr };
+    unsigned h_stage_next = 0;
+    size_t host_stage_max = (size_t)8 << 20; // BBGPU_STAGE_MAX_BYTES: larger buffers are handed to hipMemcpyAsync as they are
 };
 
 std::recursive_mutex g_mu;
@@ -113,6 +120,7 @@ void read_host_env()
     g_ctx.host_env_read = true;
     if (const char* e = getenv("BBGPU_HOST_MSM_MAX")) g_ctx.host_msm_max = atoi(e);
     if (const char* e = getenv("BBGPU_HOST_NTT_MAX")) g_ctx.host_ntt_max = std::min(64, atoi(e));
+    if (const char* e = getenv("BBGPU_STAGE_MAX_BYTES")) g_ctx.host_stage_max = (size_t)strtoull(e, nullptr, 0);
 }
 
 int ensure_init()
@@ -159,10 +167,105 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
     return BBGPU_OK;
 }
 
+} // namespace
+
+// ---- the callers' host buffers ------------------------------------------------------------------------------------------------------
+// A pageable buffer handed to hipMemcpyAsync is pinned in place by the runtime (a userptr mapping it keeps for later copies).  That is
+// the fastest path while the caller keeps its buffers -- and a trap when it does not: the reference's Prover allocates its polynomials
+// per proof, and when such a pinned range is unmapped the driver quiesces and later restores the process's GPU queues.  Seen from the
+// unmodified reference prover linked on the shim (tools/shim_profile.py, BBGPU_TRACE_SRS=1): from the second proof of a process on, one
+// hipMemcpyAsync per proof BLOCKED for 6-23 ms (a 2 MiB upload; of a 64 ms proof).  So buffers up to `host_stage_max` (8 MiB: every
+// polynomial of a 2^16-gate proof, its 4n-coset vectors and its 8 MiB point table) cross through two pinned 4 MiB buffers of the
+// library's own: CPU memcpy (30-50 GB/s on the boxes' EPYC 9575F), DMA from / to pinned memory, the copy of chunk k+1 under the DMA of
+// chunk k.  Larger buffers keep the direct path: there a copy is 0.6 ms per 32 MiB against ~1 ms through one staging thread, and the
+// stall is small against the work (profiles/r03_pcie.txt).
+int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
+{
+    read_host_env();
+    if (bytes == 0) return BBGPU_OK;
+    if (bytes > g_ctx.host_stage_max) {
+        CHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+        return BBGPU_OK;
+    }
+    const size_t CH = Context::HOST_CHUNK;
+    for (int k = 0; k < 2; k++)
+        if (!g_ctx.h_stage[k]) {
+            CHK(hipHostMalloc(&g_ctx.h_stage[k], CH, hipHostMallocDefault));
+            CHK(hipEventCreateWithFlags(&g_ctx.h_stage_free[k], hipEventDisableTiming));
+        }
+    for (size_t off = 0; off < bytes; off += CH) {
+        const size_t len = std::min(CH, bytes - off);
+        const int k = (int)(g_ctx.h_stage_next++ & 1);
+        CHK(hipEventSynchronize(g_ctx.h_stage_free[k])); // the DMA that last read this buffer has finished (no-op before its first use)
+        memcpy(g_ctx.h_stage[k], (const char*)h_src + off, len);
+        CHK(hipMemcpyAsync((char*)d_dst + off, g_ctx.h_stage[k], len, hipMemcpyHostToDevice, st));
+        CHK(hipEventRecord(g_ctx.h_stage_free[k], st));
+    }
+    return BBGPU_OK;
+}
+// device -> caller's buffer, complete on return (everything enqueued on `st` before it has run as well)
+int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st)
+{
+    read_host_env();
+    if (bytes > g_ctx.host_stage_max) {
+        CHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        CHK(hipStreamSynchronize(st));
+        return BBGPU_OK;
+    }
+    const size_t CH = Context::HOST_CHUNK;
+    for (int k = 0; k < 2; k++)
+        if (!g_ctx.h_stage[k]) {
+            CHK(hipHostMalloc(&g_ctx.h_stage[k], CH, hipHostMallocDefault));
+            CHK(hipEventCreateWithFlags(&g_ctx.h_stage_free[k], hipEventDisableTiming));
+        }
+    // chunk c+1 is on the link while chunk c is copied out of its pinned buffer
+    const size_t chunks = (bytes + CH - 1) / CH;
+    int kbuf[2] = { 0, 0 };
+    auto enqueue = [&](size_t c) -> int {
+        const int k = (int)(g_ctx.h_stage_next++ & 1);
+        kbuf[c & 1] = k;
+        CHK(hipEventSynchronize(g_ctx.h_stage_free[k]));
+        CHK(hipMemcpyAsync(g_ctx.h_stage[k], (const char*)d_src + c * CH, std::min(CH, bytes - c * CH), hipMemcpyDeviceToHost, st));
+        CHK(hipEventRecord(g_ctx.h_stage_free[k], st));
+        return BBGPU_OK;
+    };
+    if (chunks == 0) {
+        CHK(hipStreamSynchronize(st));
+        return BBGPU_OK;
+    }
+    if (int rc = enqueue(0)) return rc;
+    for (size_t c = 0; c < chunks; c++) {
+        if (c + 1 < chunks)
+            if (int rc = enqueue(c + 1)) return rc;
+        const int k = kbuf[c & 1];
+        CHK(hipEventSynchronize(g_ctx.h_stage_free[k]));
+        memcpy((char*)h_dst + c * CH, g_ctx.h_stage[k], std::min(CH, bytes - c * CH));
+    }
+    return BBGPU_OK;
+}
+void host_stage_release()
+{
+    for (int k = 0; k < 2; k++) {
+        if (g_ctx.h_stage[k]) (void)hipHostFree(g_ctx.h_stage[k]);
+        if (g_ctx.h_stage_free[k]) (void)hipEventDestroy(g_ctx.h_stage_free[k]);
+        g_ctx.h_stage[k] = nullptr;
+        g_ctx.h_stage_free[k] = nullptr;
+    }
+}
+
+namespace {
+
 constexpr size_t AUTO_REGISTER_MIN_POINTS = 1024; // host-pointer MSMs against unknown tables below this size do not cache the table
 
+// BBGPU_TRACE_SRS=1: one line on stderr per event of the address-keyed point-table cache (register, evict, content mismatch)
+bool trace_srs()
+{
+    static const bool on = getenv("BBGPU_TRACE_SRS") != nullptr;
+    return on;
+}
 void free_entry(SrsEntry& e)
 {
+    if (trace_srs()) fprintf(stderr, "bbgpu srs: evict %p n=%zu auto=%d\n", (const void*)e.host_ptr, e.n, (int)e.auto_registered);
     // an asynchronous MSM may still be reading the table: drain the device first (rare path)
     (void)hipDeviceSynchronize();
     if (e.d_srs) (void)hipFree(e.d_srs);
@@ -183,6 +286,7 @@ bool ranges_overlap(const SrsEntry& e, const uint64_t* p, size_t n)
 // the least recently used ones beyond the byte cap.
 int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_registered)
 {
+    if (trace_srs()) fprintf(stderr, "bbgpu srs: register %p n=%zu auto=%d\n", (const void*)host_ptr, n, (int)auto_registered);
     SrsEntry e;
     e.host_ptr = host_ptr;
     e.n = n;
@@ -300,6 +404,7 @@ int find_srs(const uint64_t* points, size_t n, size_t* offset)
         if (d % 128) continue;
         if (d / 128 + n > e.n) continue;
         if (!contents_match(e, d / 128, points, n)) {
+            if (trace_srs()) fprintf(stderr, "bbgpu srs: contents of %p (+%zu rows, n=%zu) differ from the resident copy\n", (const void*)e.host_ptr, d / 128, n);
             if (e.auto_registered) free_entry(e);
             continue;
         }
@@ -368,14 +473,55 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         off = 0;
     }
     const SrsEntry& e = is_transient ? transient : g_ctx.srs[idx];
-    int rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
-    if (rc == BBGPU_OK && hipMemcpyAsync(g_ctx.d_stage, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess) {
-        set_error("scalar upload failed");
-        rc = BBGPU_ERR_HIP;
-    }
     host::Xyzz res;
-    if (rc == BBGPU_OK) rc = issue_on_entry(g_ctx.slot[0], e, off, g_ctx.d_stage, n, 0, entry_windows(e, n), g_ctx.stream);
-    if (rc == BBGPU_OK) rc = msm_finish(g_ctx.slot[0], &res, &g_ctx.last);
+    int rc = BBGPU_OK;
+    // A large MSM is cut into point ranges that go through the two-slot pipeline like the jobs of a batch: the scalars of range k+1
+    // cross the link while the kernels of range k run, and the partial sums (group elements: the sum over a range of points is a
+    // plain term of the whole sum) are added on the host.  One 2^20-point call: 32 MiB of scalars = 0.6 ms on the link before the
+    // first kernel, against 0.15 ms for the first of four ranges (bench.py `boundary`).  BBGPU_HOST_MSM_SPLIT=1 restores one range.
+    static const size_t split_env = [] { const char* v = getenv("BBGPU_HOST_MSM_SPLIT"); return v ? (size_t)std::max(1, atoi(v)) : (size_t)0; }();
+    // Measured on MI355X (tools/boundary_ab.py, 2^20 points): one range 2.05-2.08 ms, two 1.77 ms, four 2.17-2.20 ms -- every range pays its
+    // own sort and bucket-reduction tail (~0.3 ms of launches that only partly hide), so two it is, the first one the smaller: its
+    // upload is the part nothing hides, and the second range's upload (0.6 ms x its share) still fits under the first one's kernels.
+    const size_t ranges = split_env ? split_env : (n >= ((size_t)1 << 19) ? 2 : 1);
+    if (ranges > 1 && !g_ctx.slot[1].pending) {
+        const size_t base = ranges == 2 ? ((n * 3 / 8) & ~(size_t)7) : n / ranges;
+        uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
+        size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
+        res = host::g1_infinity();
+        auto finish = [&](size_t k) -> int {
+            host::Xyzz part;
+            int r = msm_finish(g_ctx.slot[k & 1], &part, k + 1 == ranges ? &g_ctx.last : nullptr);
+            if (r == BBGPU_OK) res = host::g1_add(res, part);
+            return r;
+        };
+        size_t issued = 0;
+        for (size_t k = 0; k < ranges && rc == BBGPU_OK; k++) {
+            const int t = (int)(k & 1);
+            MsmSlot& S = g_ctx.slot[t];
+            const size_t o = k * base, len = (k + 1 == ranges) ? n - o : base;
+            rc = grow(stage[t], cap[t], (n - (ranges - 1) * base) * 32);
+            if (rc == BBGPU_OK && !S.stream && hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) {
+                set_error("stream creation failed");
+                rc = BBGPU_ERR_HIP;
+            }
+            if (rc == BBGPU_OK) rc = host_to_device(*stage[t], scalars + o * 4, len * 32, S.stream);
+            if (rc == BBGPU_OK) rc = issue_on_entry(S, e, off + o, *stage[t], len, 0, entry_windows(e, len), S.stream);
+            if (rc == BBGPU_OK) issued = k + 1;
+            if (rc == BBGPU_OK && k >= 1) rc = finish(k - 1);
+        }
+        if (rc == BBGPU_OK) rc = finish(ranges - 1);
+        else { // drain whatever is still in flight so that the slots are usable again
+            host::Xyzz dump;
+            for (size_t k = issued >= 2 ? issued - 2 : 0; k < issued; k++)
+                if (g_ctx.slot[k & 1].pending) (void)msm_finish(g_ctx.slot[k & 1], &dump, nullptr);
+        }
+    } else {
+        rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
+        if (rc == BBGPU_OK) rc = host_to_device(g_ctx.d_stage, scalars, n * 32, g_ctx.stream);
+        if (rc == BBGPU_OK) rc = issue_on_entry(g_ctx.slot[0], e, off, g_ctx.d_stage, n, 0, entry_windows(e, n), g_ctx.stream);
+        if (rc == BBGPU_OK) rc = msm_finish(g_ctx.slot[0], &res, &g_ctx.last);
+    }
     if (is_transient) (void)hipFree(transient.d_srs); // msm_finish has waited for the kernels
     if (rc) return rc;
     host::g1_to_normalised(res, out);
@@ -417,6 +563,7 @@ void bbgpu_shutdown(void)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g_ctx.ready) return;
     plonk_release_all();
+    host_stage_release();
     (void)hipStreamSynchronize(g_ctx.stream);
     g_ctx.poly_scratch.release();
     if (g_ctx.d_poly_tmp) (void)hipFree(g_ctx.d_poly_tmp);
@@ -520,12 +667,10 @@ int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
     if (rc) return rc;
     rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
     if (rc) return rc;
-    CHK(hipMemcpyAsync(g_ctx.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+    if ((rc = host_to_device(g_ctx.d_stage, coeffs, n * 32, g_ctx.stream)) != BBGPU_OK) return rc;
     rc = bbgpu_ntt_device(g_ctx.d_stage, n, kind, constant, g_ctx.stream);
     if (rc) return rc;
-    CHK(hipMemcpyAsync(coeffs, g_ctx.d_stage, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
-    CHK(hipStreamSynchronize(g_ctx.stream));
-    return BBGPU_OK;
+    return device_to_host_sync(coeffs, g_ctx.d_stage, n * 32, g_ctx.stream);
 }
 
 /* ---- resident polynomial helpers ---- */
@@ -645,14 +790,11 @@ static int stage_in(const uint64_t* host, size_t n)
 {
     int rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
     if (rc) return rc;
-    CHK(hipMemcpyAsync(g_ctx.d_stage, host, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
-    return BBGPU_OK;
+    return host_to_device(g_ctx.d_stage, host, n * 32, g_ctx.stream);
 }
 static int stage_out(uint64_t* host, const uint64_t* dev, size_t n)
 {
-    CHK(hipMemcpyAsync(host, dev, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
-    CHK(hipStreamSynchronize(g_ctx.stream));
-    return BBGPU_OK;
+    return device_to_host_sync(host, dev, n * 32, g_ctx.stream);
 }
 
 int bbgpu_fr_evaluate(const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4])
@@ -996,7 +1138,10 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
     // cross PCIe and its kernels are enqueued while job i's bucket-reduction tail and host finish run.
     uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
     size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
+    auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const bool tr = trace_srs();
     auto issue = [&](size_t i) -> int {
+        const double q0 = tr ? now_ms() : 0;
         const int t = (int)(i & 1);
         MsmSlot& S = g_ctx.slot[t];
         if (!jobs[i].scalars || !jobs[i].points) {
@@ -1012,11 +1157,15 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
             idx = add_srs(jobs[i].points, n, d, true);
             if (idx < 0) return idx;
         }
+        const double q1 = tr ? now_ms() : 0;
         int r = grow(stage[t], cap[t], n * 32);
         if (r) return r;
         if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-        CHK(hipMemcpyAsync(*stage[t], jobs[i].scalars, n * 32, hipMemcpyHostToDevice, S.stream));
-        return issue_on_entry(S, g_ctx.srs[idx], off, *stage[t], n, 0, entry_windows(g_ctx.srs[idx], n), S.stream);
+        if ((r = host_to_device(*stage[t], jobs[i].scalars, n * 32, S.stream)) != BBGPU_OK) return r;
+        const double q2 = tr ? now_ms() : 0;
+        r = issue_on_entry(S, g_ctx.srs[idx], off, *stage[t], n, 0, entry_windows(g_ctx.srs[idx], n), S.stream);
+        if (tr) fprintf(stderr, "bbgpu batch: job %zu srs %.3f, copy call %.3f, kernel launches %.3f ms\n", i, q1 - q0, q2 - q1, now_ms() - q2);
+        return r;
     };
     auto finish = [&](size_t i) -> int {
         host::Xyzz res;
@@ -1026,10 +1175,16 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
         return BBGPU_OK;
     };
     for (size_t i = 0; i < num_jobs; i++) {
+        const double t0 = tr ? now_ms() : 0;
         if ((rc = issue(i)) != BBGPU_OK) return rc;
+        const double t1 = tr ? now_ms() : 0;
         if (i >= 1 && (rc = finish(i - 1)) != BBGPU_OK) return rc;
+        if (tr) fprintf(stderr, "bbgpu batch: job %zu issue %.3f ms, finish(prev) %.3f ms\n", i, t1 - t0, now_ms() - t1);
     }
-    return finish(num_jobs - 1);
+    const double t2 = tr ? now_ms() : 0;
+    rc = finish(num_jobs - 1);
+    if (tr) fprintf(stderr, "bbgpu batch: last finish %.3f ms\n", now_ms() - t2);
+    return rc;
 }
 
 int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin, int window_end,

@@ -1770,7 +1770,11 @@ int srs_upload(const uint64_t* host_table, size_t n, uint32_t** d_srs_out, hipSt
     uint32_t* d_srs = nullptr;
     HIPCHK(hipMalloc((void**)&d_tab, n * stride_bytes));
     HIPCHK(hipMalloc((void**)&d_srs, n * 64));
-    HIPCHK(hipMemcpyAsync(d_tab, host_table, n * stride_bytes, hipMemcpyHostToDevice, st));
+    if (int rc = host_to_device(d_tab, host_table, n * stride_bytes, st)) {
+        (void)hipFree(d_tab);
+        (void)hipFree(d_srs);
+        return rc;
+    }
     srs_convert_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_tab, d_srs, (uint32_t)n, (uint32_t)(stride_bytes / 4));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -1817,8 +1821,10 @@ int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint
         uint32_t* d_exp = nullptr;
         HIPCHK(hipMalloc((void**)&d_exp, n * 128));
         srs_export_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_srs, d_exp, (uint32_t)n);
-        HIPCHK(hipMemcpyAsync(host_table_out, d_exp, n * 128, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if (int rc = device_to_host_sync(host_table_out, d_exp, n * 128, st)) {
+            (void)hipFree(d_exp);
+            return rc;
+        }
         HIPCHK(hipFree(d_exp));
     }
     HIPCHK(hipStreamSynchronize(st));

@@ -172,8 +172,8 @@ class PlonkProver {
             s_fft[k] = s_fft[0] + (size_t)k * 4 * n * 4;
             RC(dalloc(&sigma_mapping[k], n * 4));
             RC(dalloc(&tmp[k], fb));
-            HIPCHK(hipMemcpy(w_lagrange[k], hw[k], fb, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(sigma_mapping[k], hm[k], n * 4, hipMemcpyHostToDevice));
+            RC(host_to_device(w_lagrange[k], hw[k], fb, st));
+            RC(host_to_device(sigma_mapping[k], hm[k], n * 4, st));
         }
         RC(dalloc(&q_lagrange[0], 5 * fb));
         RC(dalloc(&q_coeff[0], 5 * fb));
@@ -182,7 +182,7 @@ class PlonkProver {
             q_lagrange[k] = q_lagrange[0] + (size_t)k * n * 4;
             q_coeff[k] = q_coeff[0] + (size_t)k * n * 4;
             q_fft2n[k] = q_fft2n[0] + (size_t)k * 2 * n * 4;
-            HIPCHK(hipMemcpy(q_lagrange[k], hq[k], fb, hipMemcpyHostToDevice));
+            RC(host_to_device(q_lagrange[k], hq[k], fb, st));
         }
         const uint64_t* hb[3] = { c->q_bl, c->q_br, c->q_bo };
         has_bool = hb[0] != nullptr;
@@ -194,7 +194,7 @@ class PlonkProver {
                 qb_lagrange[k] = qb_lagrange[0] + (size_t)k * n * 4;
                 qb_coeff[k] = qb_coeff[0] + (size_t)k * n * 4;
                 qb_fft2n[k] = qb_fft2n[0] + (size_t)k * 2 * n * 4;
-                HIPCHK(hipMemcpy(qb_lagrange[k], hb[k], fb, hipMemcpyHostToDevice));
+                RC(host_to_device(qb_lagrange[k], hb[k], fb, st));
             }
         }
         const uint64_t* hmm[2] = { c->q_mimc_selector, c->q_mimc_coefficient };
@@ -207,7 +207,7 @@ class PlonkProver {
                 qm_lagrange[k] = qm_lagrange[0] + (size_t)k * n * 4;
                 qm_coeff[k] = qm_coeff[0] + (size_t)k * n * 4;
                 qm_fft4n[k] = qm_fft4n[0] + (size_t)k * 4 * n * 4;
-                HIPCHK(hipMemcpy(qm_lagrange[k], hmm[k], fb, hipMemcpyHostToDevice));
+                RC(host_to_device(qm_lagrange[k], hmm[k], fb, st));
             }
         }
         has_seq = c->q_o_next != nullptr;
@@ -215,7 +215,7 @@ class PlonkProver {
             RC(dalloc(&qs_lagrange, fb));
             RC(dalloc(&qs_coeff, fb));
             RC(dalloc(&qs_fft2n, 2 * fb));
-            HIPCHK(hipMemcpy(qs_lagrange, c->q_o_next, fb, hipMemcpyHostToDevice));
+            RC(host_to_device(qs_lagrange, c->q_o_next, fb, st));
         }
         RC(dalloc(&roots, fb));
         RC(dalloc(&l_1, 2 * fb));
@@ -226,12 +226,14 @@ class PlonkProver {
         RC(dalloc(&r, fb));
         RC(dalloc(&slots, 16 * 32));
         HIPCHK(hipHostMalloc(&h_slots, 16 * 32));
+        HIPCHK(hipStreamSynchronize(st)); // the caller's arrays may go away after this call (uploads above 8 MiB read them asynchronously)
         return BBGPU_OK;
     }
     int set_witness(const uint64_t* wl, const uint64_t* wr, const uint64_t* wo)
     {
         const uint64_t* hw[3] = { wl, wr, wo };
-        for (int k = 0; k < 3; k++) HIPCHK(hipMemcpy(w_lagrange[k], hw[k], n * 32, hipMemcpyHostToDevice));
+        for (int k = 0; k < 3; k++) RC(host_to_device(w_lagrange[k], hw[k], n * 32, st));
+        HIPCHK(hipStreamSynchronize(st));
         return BBGPU_OK;
     }
 

@@ -38,12 +38,78 @@
 #include "../csrc/host_g1.hpp"
 #include "../csrc/host_wnaf.hpp"
 
+#include <chrono>
+
 namespace {
 [[noreturn]] void die(const char* what, int rc)
 {
     std::fprintf(stderr, "bbgpu shim: %s failed (%d): %s\n", what, rc, bbgpu_last_error());
     std::abort();
 }
+
+// Accounting of the drop-in path (BBGPU_SHIM_PROFILE=<file> or =1 for stderr; off by default, one branch per call when off): for every
+// symbol the calls, the wall time spent inside it and the bytes its host buffers sent over the link each way, written as one JSON
+// object when the process ends.  A caller's own timer around construct_proof() minus `total_ms` is then the reference's own host code;
+// bytes / the link rate (tools/ubench/ubench_pcie: 56 GB/s either way on the MI355X boxes) is the part of `ms` that is PCIe.
+struct ShimProfile {
+    struct Row { const char* name; unsigned long long calls, up, down; double ms; };
+    Row rows[48];
+    int n = 0;
+    const char* path = nullptr;
+    ShimProfile() { path = std::getenv("BBGPU_SHIM_PROFILE"); if (path && !*path) path = nullptr; }
+    Row& row(const char* name)
+    {
+        for (int i = 0; i < n; i++) if (rows[i].name == name) return rows[i]; // string literals: one address per call site
+        if (n == 47) return rows[47];
+        rows[n] = Row{ name, 0, 0, 0, 0.0 };
+        return rows[n++];
+    }
+    bool written = false;
+    void write(const char* tag, double caller_ms)
+    {
+        if (!path) return;
+        FILE* f = std::strcmp(path, "1") ? std::fopen(path, written ? "a" : "w") : stderr;
+        if (!f) return;
+        written = true;
+        double total = 0;
+        unsigned long long up = 0, down = 0;
+        for (int i = 0; i < n; i++) { total += rows[i].ms; up += rows[i].up; down += rows[i].down; }
+        std::fprintf(f, "{\"region\": \"%s\", \"caller_ms\": %.3f, \"inside_shim_ms\": %.3f, \"h2d_bytes\": %llu, \"d2h_bytes\": %llu, \"symbols\": {", tag, caller_ms, total, up, down);
+        for (int i = 0; i < n; i++)
+            std::fprintf(f, "%s\"%s\": {\"calls\": %llu, \"ms\": %.3f, \"h2d_bytes\": %llu, \"d2h_bytes\": %llu}", i ? ", " : "", rows[i].name, rows[i].calls, rows[i].ms,
+                         rows[i].up, rows[i].down);
+        std::fprintf(f, "}}\n");
+        if (f != stderr) std::fclose(f);
+    }
+    ~ShimProfile() { if (!written) write("process", 0.0); }
+};
+ShimProfile g_prof;
+} // namespace
+// for a caller that wants the accounting of ONE region (oracle/plonk_driver.cpp around construct_proof()): weak references on its side
+extern "C" __attribute__((visibility("default"))) void bbshim_profile_reset(void) { g_prof.n = 0; }
+extern "C" __attribute__((visibility("default"))) void bbshim_profile_write(const char* tag, double caller_ms) { g_prof.write(tag, caller_ms); }
+namespace {
+struct Prof {
+    ShimProfile::Row* r = nullptr;
+    std::chrono::steady_clock::time_point t0;
+    Prof(const char* name, size_t up, size_t down)
+    {
+        if (!g_prof.path) return;
+        r = &g_prof.row(name);
+        r->calls++;
+        r->up += up;
+        r->down += down;
+        t0 = std::chrono::steady_clock::now();
+    }
+    ~Prof()
+    {
+        if (!r) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        r->ms += ms;
+        static const bool trace = std::getenv("BBGPU_SHIM_TRACE") != nullptr; // one line per call
+        if (trace) std::fprintf(stderr, "bbshim %s %.3f ms\n", r->name, ms);
+    }
+};
 } // namespace
 
 namespace barretenberg {
@@ -54,6 +120,7 @@ g1::element pippenger(fr::field_t* scalars, g1::affine_element* points, size_t n
     // the bucket width is a tuning knob of the CPU algorithm (get_optimal_bucket_width); every width yields the same
     // group element, and the GPU path picks its own window size
     g1::element out;
+    Prof prof("pippenger", num_initial_points * 32, 96); // + the point table the first time it is seen
     int rc = bbgpu_msm_g1(reinterpret_cast<const uint64_t*>(scalars), reinterpret_cast<const uint64_t*>(points), num_initial_points,
                           reinterpret_cast<uint64_t*>(&out));
     if (rc != BBGPU_OK) die("pippenger", rc);
@@ -69,12 +136,14 @@ void batched_scalar_multiplications(multiplication_state* mul_state, size_t num_
             return;
         }
     }
+    Prof prof("batched_scalar_multiplications", num_batches ? num_batches * mul_state[0].num_elements * 32 : 0, num_batches * 96);
     int rc = bbgpu_msm_g1_batch(reinterpret_cast<bbgpu_msm_job*>(mul_state), num_batches);
     if (rc != BBGPU_OK) die("batched_scalar_multiplications", rc);
 }
 
 void generate_pippenger_point_table(g1::affine_element* points, g1::affine_element* table, size_t num_points)
 {
+    Prof prof("generate_pippenger_point_table", num_points * 64, num_points * 128);
     int rc = bbgpu_generate_point_table(reinterpret_cast<const uint64_t*>(points), reinterpret_cast<uint64_t*>(table), num_points);
     if (rc != BBGPU_OK) die("generate_pippenger_point_table", rc);
 }
@@ -248,6 +317,8 @@ namespace polynomial_arithmetic {
 namespace {
 void run(fr::field_t* coeffs, const evaluation_domain& domain, int kind, const fr::field_t* c)
 {
+    static const char* const names[] = { "fft", "ifft", "coset_fft", "coset_ifft", "fft_with_constant", "ifft_with_constant", "coset_fft_with_constant" };
+    Prof prof(names[kind], domain.size * 32, domain.size * 32);
     int rc = bbgpu_ntt(reinterpret_cast<uint64_t*>(coeffs), domain.size, kind, c ? reinterpret_cast<const uint64_t*>(c->data) : nullptr);
     if (rc != BBGPU_OK) die("fft", rc);
 }
@@ -263,6 +334,7 @@ void coset_fft_with_constant(fr::field_t* coeffs, const evaluation_domain& domai
 fr::field_t evaluate(const fr::field_t* coeffs, const fr::field_t& z, const size_t n)
 {
     fr::field_t r;
+    Prof prof("evaluate", n * 32, 32);
     int rc = bbgpu_fr_evaluate(reinterpret_cast<const uint64_t*>(coeffs), n, z.data, r.data);
     if (rc != BBGPU_OK) die("evaluate", rc);
     return r;
@@ -270,23 +342,27 @@ fr::field_t evaluate(const fr::field_t* coeffs, const fr::field_t& z, const size
 void copy_polynomial(fr::field_t* src, fr::field_t* dest, size_t num_src_coefficients, size_t num_target_coefficients)
 {
     // :23-35: copy, then zero the tail of the (longer) destination
+    Prof prof("copy_polynomial", 0, 0);
     std::memcpy(dest, src, num_src_coefficients * sizeof(fr::field_t));
     if (num_target_coefficients > num_src_coefficients)
         std::memset(dest + num_src_coefficients, 0, (num_target_coefficients - num_src_coefficients) * sizeof(fr::field_t));
 }
 void compute_lagrange_polynomial_fft(fr::field_t* l_1_coefficients, const evaluation_domain& src_domain, const evaluation_domain& target_domain)
 {
+    Prof prof("compute_lagrange_polynomial_fft", 0, target_domain.size * 32);
     int rc = bbgpu_lagrange_l1_fft(reinterpret_cast<uint64_t*>(l_1_coefficients), src_domain.size, target_domain.size);
     if (rc != BBGPU_OK) die("compute_lagrange_polynomial_fft", rc);
 }
 void divide_by_pseudo_vanishing_polynomial(fr::field_t* coeffs, const evaluation_domain& src_domain, const evaluation_domain& target_domain)
 {
+    Prof prof("divide_by_pseudo_vanishing_polynomial", target_domain.size * 32, target_domain.size * 32);
     int rc = bbgpu_divide_by_pseudo_vanishing(reinterpret_cast<uint64_t*>(coeffs), src_domain.size, target_domain.size);
     if (rc != BBGPU_OK) die("divide_by_pseudo_vanishing_polynomial", rc);
 }
 fr::field_t compute_kate_opening_coefficients(const fr::field_t* src, fr::field_t* dest, const fr::field_t& z, const size_t n)
 {
     fr::field_t f;
+    Prof prof("compute_kate_opening_coefficients", n * 32, n * 32);
     int rc = bbgpu_kate_opening(reinterpret_cast<const uint64_t*>(src), reinterpret_cast<uint64_t*>(dest), n, z.data, f.data);
     if (rc != BBGPU_OK) die("compute_kate_opening_coefficients", rc);
     return f;
@@ -295,12 +371,14 @@ lagrange_evaluations get_lagrange_evaluations(const fr::field_t& z, const evalua
 {
     lagrange_evaluations r;
     static_assert(sizeof(lagrange_evaluations) == 96, "three field elements");
+    Prof prof("get_lagrange_evaluations", 0, 0);
     int rc = bbgpu_lagrange_evaluations(z.data, domain.size, reinterpret_cast<uint64_t*>(&r));
     if (rc != BBGPU_OK) die("get_lagrange_evaluations", rc);
     return r;
 }
 void compress_fft(const fr::field_t* src, fr::field_t* dest, const size_t current_size, const size_t compress_factor)
 {
+    Prof prof("compress_fft", 0, 0);
     size_t log2_factor = 0;
     while (((size_t)1 << log2_factor) < compress_factor) ++log2_factor;
     const size_t new_size = current_size >> log2_factor;
