@@ -270,6 +270,25 @@ def plonk_leg(G, args, gates=65536, reps=10):
                             "proof_bit_exact": ref_lines[:26] == proof_lines(state["n"], first)}
         if m:
             out["speedup_vs_reference_cpu"] = float(m.group(1)) / out["ms"]
+        # the drop-in path north_star names: the reference's UNMODIFIED prover, its hot-path symbols resolved by libbbshim.so -> libbbgpu.so
+        # (oracle/_ref/plonk_gpu, a child process; third proof of that process = steady state), with the shim's own accounting of where the
+        # time goes: caller_ms - inside_shim_ms is the reference's own host code
+        exe_gpu = os.path.join(ROOT, "oracle", "_ref", "plonk_gpu")
+        if os.path.exists(exe_gpu):
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".json") as tf:
+                r2 = subprocess.run([exe_gpu, "prove", str(gates)], cwd=ROOT, capture_output=True, text=True,
+                                    env=dict(os.environ, OMP_NUM_THREADS=str(threads), BB_WARM_PROOFS="2", BBGPU_SHIM_PROFILE=tf.name))
+                m2 = re.search(r"construct_proof ([0-9.]+) ms", r2.stderr)
+                try:
+                    prof = json.loads(open(tf.name).read().strip().split("\n")[0])
+                except Exception:
+                    prof = None
+            if m2:
+                out["reference_prover_on_shim"] = {"ms": float(m2.group(1)), "cores": threads, "proof_bit_exact": r2.stdout.strip().split("\n")[:26] == ref_lines[:26],
+                                                   "inside_shim_ms": prof and prof.get("inside_shim_ms"), "reference_host_code_ms": prof and (prof["caller_ms"] - prof["inside_shim_ms"]),
+                                                   "h2d_bytes": prof and prof.get("h2d_bytes"), "d2h_bytes": prof and prof.get("d2h_bytes"),
+                                                   "note": "third proof of the child process (BB_WARM_PROOFS=2); breakdown per symbol: profiles/r03_shim_profile_2e16.json"}
     P.destroy()
     G.srs_release(srs)
     return out
@@ -381,10 +400,14 @@ def main():
     host_legs = single and not args.no_boundary   # boundary-inclusive legs need the host copy of the point table
     if world > 1 and not args.no_window_tables:
         G.set_table_share(rank, world)  # this rank's 1/N of the (window, point) rows touches ceil(W / N) + 1 digit windows: only those are built and kept
+    torch.cuda.synchronize()
+    t_srs0 = time.perf_counter()
     if cpu_leg or host_legs:
         srs, table = G.srs_generate(x_secret, n, want_host_table=True)
     else:
         srs, table = G.srs_generate(x_secret, n), None
+    torch.cuda.synchronize()
+    srs_setup_ms = (time.perf_counter() - t_srs0) * 1e3  # one-time: points generated, window tables built (and the host copy written when asked for)
     G.set_table_share(0, 1)
     d_scalars = to_montgomery_on_device(G, raw_scalars(n, SPLITMIX_GAMMA), dev)
     scalars = d_scalars.cpu().numpy().view(np.uint64) if (cpu_leg or host_legs) else None
@@ -394,6 +417,7 @@ def main():
 
     # with window tables (one shared bucket set) the W * n (window, point) pairs split at ANY row, so every rank takes exactly 1/N of them
     # even when N does not divide W (15 windows of 17 bits at 2^20); without tables the split follows whole windows
+    wb_tab, we_tab = (W * rank // world, -(-W * (rank + 1) // world)) if world > 1 else (0, W)  # digit windows whose tables this rank keeps
     by_rows = world > 1 and G.srs_has_window_tables(srs)
     rows = (W * n * rank // world, W * n * (rank + 1) // world)
 
@@ -585,20 +609,33 @@ def main():
         # HBM bytes per launch from the PMC passes of the SAME binary (profiles/, tools/pmc_summary.py), corrected by the factor the
         # gather calibration kernel of known traffic gave for this access shape
         traffic = ntt_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(tpath):
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % t) for t in ("r03", "r02")) if os.path.exists(q)), "")
+        if tpath:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("msm_accumulate_kernel_bytes_per_launch")
                 ntt_traffic = tj.get("ntt_2e20_bytes_per_transform")
             except Exception:
                 traffic = None
+        # the same fraction from the committed rocprofv3 trace of this command (profiles/: spacing of consecutive accumulation dispatches'
+        # end times, tools/acc_spacing.py), so that the live figure and the profile can be compared without reading profiles/README.md
+        rocprof_spacing_ms = rocprof_frac = None
+        for tag in ("r03", "r02"):
+            sp = os.path.join(ROOT, "profiles", "%s_acc_spacing.txt" % tag)
+            if os.path.exists(sp):
+                import re
+                m = re.search(r"spacing[^0-9]*([0-9.]+) ms", open(sp).read())
+                if m:
+                    rocprof_spacing_ms = float(m.group(1))
+                    rocprof_frac = alg_bytes / (rocprof_spacing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                break
         share_adds = (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation
-        # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition = 738 v_mad_u64_u32 with two VGPR factors
-        # + 729 with an SGPR factor + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 209 v_and_b32 + ~430 other VALU, priced at the measured
-        # chip-wide issue rates of tools/ubench/ubench_inst (445 / 489 / 565 / 537 / 916 / ~850 G wave-instructions/s): 4.24 ns of chip time per
-        # wave-addition = the floor this instruction stream allows
-        ns_per_wave_add = 738 / 445.0 + 729 / 489.0 + 144 / 565.0 + 81 / 537.0 + 209 / 916.0 + 430 / 850.0
+        # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition (round-3 loop: 2,142 instructions in the hot
+        # path + ~85 in the bucket-start block that ~1 trip in 4 runs) = 738 v_mad_u64_u32 with two VGPR factors + 729 with an SGPR factor
+        # + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 194 v_and_b32 + ~275 other VALU, priced at the measured chip-wide issue rates of
+        # tools/ubench/ubench_inst (445 / 489 / 565 / 537 / 916 / ~850 G wave-instructions/s): 4.04 ns of chip time per wave-addition = the
+        # floor this instruction stream allows (round 2: 209 ands, ~430 others, 4.24 ns)
+        ns_per_wave_add = 738 / 445.0 + 729 / 489.0 + 144 / 565.0 + 81 / 537.0 + 194 / 916.0 + 275 / 850.0
         issue_floor_ms = share_adds / 64 * ns_per_wave_add * 1e-6
         line = {
             "metric": "BN254 G1 MSM points/sec at n=2^%d (Fr NTT elems/sec in 'ntt')" % args.log2n,
@@ -617,7 +654,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u32x9 (256-bit Montgomery, 29-bit limbs)",
             "data": "synthetic",
+            "value_boundary": (n / (boundary["msm_g1_2e20"]["ms"] * 1e-3)) if boundary is not None else None,  # points/s through the host-pointer drop-in call bbgpu_msm_g1, PCIe included
             "config": {"workload": "2^%d-point BN254 G1 MSM, splitmix64 scalars (< 2^252, Montgomery form) vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
+                       "one_time_costs": {"note": "paid once per SRS / per transform size, excluded from every timed figure",
+                                          "srs_setup_ms": srs_setup_ms, "srs_setup_what": "bbgpu_srs_generate: points + window tables" + (" + host copy of the point table" if table is not None else ""),
+                                          "srs_table_bytes": int(min(we_tab - wb_tab, W) * n * 64) if not args.no_window_tables and W * n <= (1 << 24) else 0, "srs_points_bytes": n * 64,
+                                          "ntt_table_bytes": int(4 * n * 32) if n <= (1 << 22) else None},
                        "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
                        "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
@@ -629,6 +671,7 @@ def main():
                                          "note": "two MSMs in flight, a separate run after the timed region with an event after every stage: stages of consecutive steps overlap, so they sum to more than ms_per_step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "msm_accumulate_kernel", "kernel_ms": acc_ms, "kernel_ms_events_raw": acc_raw_ms, "kernel_ms_alone": float(stage[3]),
+                         "frac_from_rocprof_spacing": rocprof_frac, "rocprof_spacing_ms": rocprof_spacing_ms,
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes,
                          "valu": {"bound": "VALU instruction issue of the mixed addition's instruction stream at the measured per-instruction rates",
                                   "floor_ms": issue_floor_ms, "achieved_ms": acc_ms, "frac": issue_floor_ms / acc_ms if acc_ms > 0 else 0.0,
