@@ -342,6 +342,19 @@ def bench_circuit(num_gates, a0, b0):
     return composer
 
 
+def zero_wire_circuit(num_gates, a0):
+    """a * 0 = 0 in every gate: w_r and w_o are identically zero, so the wire commitments W_R and W_O are the point at infinity
+    (mirror of build_zero_wire_circuit in oracle/plonk_driver.cpp; tests/golden/infinity_commitments.json)"""
+    composer = StandardComposer()
+    zero_idx = composer.add_variable(0)
+    a = a0 % FR_MODULUS
+    for _ in range(num_gates):
+        ai = composer.add_variable(a)
+        composer.create_mul_gate(ai, zero_idx, zero_idx, 1, -1, 0)
+        a = (a * a + 1) % FR_MODULUS
+    return composer
+
+
 class _Circuit(C.Structure):
     _fields_ = [("n", C.c_size_t)] + [(k, C.c_void_p) for k in ("w_l", "w_r", "w_o", "sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping",
                                                                "q_m", "q_l", "q_r", "q_o", "q_c", "q_bl", "q_br", "q_bo",

@@ -247,9 +247,26 @@ void build_extended_circuit(waffle::ExtendedComposer& composer, size_t num_gates
         b = fr::sqr(c);
     }
 }
+// a circuit whose w_r and w_o are identically zero (a * 0 = 0 in every gate): the wire commitments W_R and W_O are the point at infinity
+// -- what does the reference put into the proof, and into the transcript hash, for it?  (tests/golden/infinity_commitments.json)
+void build_zero_wire_circuit(waffle::StandardComposer& composer, size_t num_gates)
+{
+    fr::field_t a = fr::to_montgomery_form({ { 0x1111111122222222ULL, 0x3333333344444444ULL, 0x5555555566666666ULL, 0x0777777788888888ULL } });
+    const uint32_t zero_idx = composer.add_variable(fr::zero);
+    for (size_t i = 0; i < num_gates; ++i) {
+        const uint32_t ai = composer.add_variable(a);
+        composer.create_mul_gate({ ai, zero_idx, zero_idx, fr::one, fr::neg_one(), fr::zero });
+        a = fr::add(fr::sqr(a), fr::one);
+    }
+}
 std::unique_ptr<waffle::ComposerBase> make_circuit(size_t num_gates)
 {
     const char* kind = getenv("BB_CIRCUIT");
+    if (kind && !strcmp(kind, "zerowire")) {
+        auto c = std::make_unique<waffle::StandardComposer>(num_gates);
+        build_zero_wire_circuit(*c, num_gates);
+        return c;
+    }
     if (kind && !strcmp(kind, "extended")) {
         auto c = std::make_unique<waffle::ExtendedComposer>(num_gates);
         build_extended_circuit(*c, num_gates);

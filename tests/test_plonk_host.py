@@ -128,3 +128,31 @@ def test_extended_composer_state_fixture_is_a_satisfied_circuit(gates):
             assert sel[i] * (w[i] * w[i] - w[i]) % FR_MODULUS == 0, i
     ids = sorted(int(v) for k in ("sigma_1_mapping", "sigma_2_mapping", "sigma_3_mapping") for v in st[k])
     assert ids == sorted(i + (t << 30) for t in range(3) for i in range(n))
+
+
+def test_reference_bytes_of_an_infinity_commitment_are_only_pinned_in_the_flag(golden):
+    """tests/golden/infinity_commitments.json (reference outputs, tools/gen_infinity_golden.py): for a commitment that is the point at
+    infinity the reference sets the flag -- bit 63 of y.data[3] (group.hpp:133-151, re-set by normalize(), :450-468) -- and leaves the rest
+    of the pair to whatever its accumulators held: the bytes change with the OpenMP thread count, in the verification key (Q_C of the
+    bench circuit) and in a proof (W_R, W_O of the zero-wire circuit), where they also change the Fiat-Shamir challenge beta and with
+    it Z_1.  Every such run verifies.  So the flag is the only thing there is to reproduce; the GPU half (what this library returns,
+    and that the reference's Verifier accepts it) is tests/test_gpu_plonk.py::test_commitments_at_infinity."""
+    fx = golden("infinity_commitments.json")
+    threads = ("1", "4", "8")
+    vk, pr = fx["verification_key_bench_circuit"], fx["proof_zerowire_circuit"]
+    for t in threads:
+        assert int(vk[t]["Q_C.y"][:16], 16) >> 63 == 1
+        assert int(pr[t]["W_R.y"][:16], 16) >> 63 == 1 and int(pr[t]["W_O.y"][:16], 16) >> 63 == 1
+        assert pr[t]["verified"] == "1"
+        # finite commitments do not depend on the thread count
+        assert vk[t]["Q_M.x"] == vk["1"]["Q_M.x"] and vk[t]["Q_M.y"] == vk["1"]["Q_M.y"]
+        assert pr[t]["W_L.x"] == pr["1"]["W_L.x"] and pr[t]["W_L.y"] == pr["1"]["W_L.y"]
+    # the bytes under the flag do
+    assert len({vk[t]["Q_C.x"] for t in threads}) > 1 and len({vk[t]["Q_C.y"] for t in threads}) > 1
+    assert len({pr[t]["W_R.x"] for t in threads}) > 1
+    # ... and they reach the transcript: beta and the commitment computed from it differ between thread counts
+    assert len({pr[t]["beta"] for t in threads}) > 1 and len({pr[t]["Z_1.x"] for t in threads}) > 1
+    # the mirror of the zero-wire circuit has two all-zero wires
+    from barretenberg_amd.plonk import zero_wire_circuit
+    st = zero_wire_circuit(32, 0x0777777788888888555555556666666633333333444444441111111122222222).preprocess()
+    assert st["n"] == fx["n"] and not np.any(st["w_r"]) and not np.any(st["w_o"]) and np.any(st["w_l"])
