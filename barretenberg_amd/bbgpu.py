@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
     "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
     "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_transcript_write", "bbgpu_msm_g1", "bbgpu_msm_g1_plain",
-    "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
+    "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_msm_g1_device_buckets_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
     "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_set_table_share", "bbgpu_selftest_field", "bbgpu_selftest_g1",
     "bbgpu_set_timing",
@@ -286,6 +286,12 @@ class BbGpu:
         window boundaries (needs the window tables); returns a ticket for msm_wait()"""
         return self._chk(self.lib.bbgpu_msm_g1_device_rows_async(handle, offset, C.c_void_p(d_scalars_ptr), n, row_begin, row_end,
                                                                 C.c_void_p(stream or 0)))
+
+    def msm_device_buckets_async(self, handle, d_scalars_ptr, n, share, share_count, offset=0, stream=None):
+        """share `share` of `share_count` of the BUCKET range (all windows, all points; needs complete window tables): 1 / N of the mixed
+        additions and 1 / N of the bucket reduction; returns a ticket for msm_wait()"""
+        self.lib.bbgpu_msm_g1_device_buckets_async.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        return self._chk(self.lib.bbgpu_msm_g1_device_buckets_async(handle, offset, C.c_void_p(d_scalars_ptr), n, share, share_count, C.c_void_p(stream or 0)))
 
     def srs_has_window_tables(self, handle):
         return self._chk(self.lib.bbgpu_srs_has_window_tables(handle)) == 1

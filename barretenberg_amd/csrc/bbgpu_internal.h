@@ -47,7 +47,10 @@ int msm_num_windows(int c);
 int msm_issue(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n, int wb,
               int we, hipStream_t st, int want_timing);
 int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
-                    size_t n, int wb, int we, hipStream_t st, int want_timing, uint32_t row_i0 = 0, uint32_t row_i1 = 0xffffffffu);
+                    size_t n, int wb, int we, hipStream_t st, int want_timing, uint32_t row_i0 = 0, uint32_t row_i1 = 0xffffffffu, uint32_t brow0 = 0,
+                    uint32_t brow1 = 0xffffffffu);
+int msm_issue_buckets(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n,
+                      uint32_t share, uint32_t share_count, hipStream_t st, int want_timing);
 int msm_issue_rows(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n,
                    uint64_t row_begin, uint64_t row_end, hipStream_t st, int want_timing);
 int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing);

@@ -1276,6 +1276,47 @@ int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t
     return t;
 }
 
+int bbgpu_msm_g1_device_buckets_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int share, int share_count, void* hip_stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (srs_handle < 0 || srs_handle >= (int)g_ctx.srs.size() || !g_ctx.srs[srs_handle].live) {
+        set_error("unknown SRS handle %d", srs_handle);
+        return BBGPU_ERR_ARG;
+    }
+    const SrsEntry& e = g_ctx.srs[srs_handle];
+    if (offset + n > e.n || !d_scalars || n == 0) {
+        set_error("MSM range [%zu, %zu) outside the registered table of %zu points", offset, offset + n, e.n);
+        return BBGPU_ERR_ARG;
+    }
+    if (!e.d_tab) {
+        set_error("bucket-range shares need the pre-shifted window tables (one shared bucket set): this table has none");
+        return BBGPU_ERR_STATE;
+    }
+    int t = -1;
+    const int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1, 2, 3 };
+    for (int k = 0; k < Context::NSLOT; k++)
+        if (!g_ctx.slot[order[k]].pending) { t = order[k]; break; }
+    if (t < 0) {
+        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
+        return BBGPU_ERR_STATE;
+    }
+    MsmSlot& S = g_ctx.slot[t];
+    if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
+    if (!windows_resident(e, 0, e.tab_W)) return BBGPU_ERR_STATE; // every share reads every window's table
+    if (share < 0 || share_count < 1 || share >= share_count) {
+        set_error("bad bucket share %d of %d", share, share_count);
+        return BBGPU_ERR_ARG;
+    }
+    rc = msm_issue_buckets(S, e.d_srs + offset * 16, e.d_tab + offset * 16, e.n, e.tab_c, d_scalars, n, (uint32_t)share, (uint32_t)share_count, st, g_ctx.timing);
+    if (rc == BBGPU_ERR_ARG) set_error("bad bucket share %d of %d (at most one share per row of the bucket matrix)", share, share_count);
+    if (rc) return rc;
+    if (t < 2) g_ctx.next_slot = t ^ 1;
+    return t;
+}
+
 int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_t* const* d_scalars, int jobs, size_t n, void* hip_stream)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);

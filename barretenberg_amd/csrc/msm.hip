@@ -364,8 +364,10 @@ constexpr uint32_t SORT_MAX_LB = 7;
 // the call in one group when the SRS carries pre-shifted window tables (the window weight is then baked into the point).
 template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, uint32_t* __restrict__ histA, uint32_t n,
                                                                 uint32_t bins, uint32_t lb, uint32_t slices, uint32_t slice_len, uint32_t win0,
-                                                                uint32_t wpg, uint32_t first_i0, uint32_t last_i1)
+                                                                uint32_t wpg, uint32_t first_i0, uint32_t last_i1, uint32_t blo, uint32_t bcnt)
 {
+    // blo, bcnt: a bucket-range share (msm_issue_buckets) keeps only the digits whose bucket lies in [blo, blo + bcnt); all three
+    // pass-A kernels apply the same test, everything after them sees a list that simply has no entries elsewhere
     FRONT_PRIO();
     __shared__ uint32_t lh[SORT_THREADS];
     const uint32_t s = blockIdx.x, wl = blockIdx.y;
@@ -382,7 +384,10 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
             load_digits8<DT>(digits + (size_t)(win0 + wl * wpg + k) * n, signs + (size_t)(win0 + wl * wpg + k) * s64, i8, d);
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if (d[j] && i8 + j >= klo && i8 + j < khi) atomicAdd(&lh[(uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1) >> lb], 1u);
+                if (d[j] && i8 + j >= klo && i8 + j < khi) {
+                    const uint32_t b = (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1);
+                    if (b - blo < bcnt) atomicAdd(&lh[b >> lb], 1u);
+                }
         }
     } else {
         for (uint32_t k = 0; k < wpg; k++) {
@@ -392,7 +397,10 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
             const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
             for (uint32_t i = klo + threadIdx.x; i < khi; i += SORT_THREADS) {
                 const int d = load_digit<DT>(dg, sg, i);
-                if (d) atomicAdd(&lh[(uint32_t)((d < 0 ? -d : d) - 1) >> lb], 1u);
+                if (d) {
+                    const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
+                    if (b - blo < bcnt) atomicAdd(&lh[b >> lb], 1u);
+                }
             }
         }
     }
@@ -468,7 +476,7 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                    uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
                                                                    uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
-                                                                   uint32_t idx_stride, uint32_t windows_per_job, uint32_t first_i0, uint32_t last_i1)
+                                                                   uint32_t idx_stride, uint32_t windows_per_job, uint32_t first_i0, uint32_t last_i1, uint32_t blo, uint32_t bcnt)
 {
     FRONT_PRIO();
     __shared__ uint32_t lc[SORT_THREADS];
@@ -492,8 +500,10 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
             for (int j = 0; j < 8; j++) {
                 if (d[j] && i8 + j >= klo && i8 + j < khi) {
                     const uint32_t b = (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1);
-                    const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
-                    tmp[pos] = (row + i8 + j) | ((b & lomask) << 24) | (d[j] < 0 ? 0x80000000u : 0u);
+                    if (b - blo < bcnt) {
+                        const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
+                        tmp[pos] = (row + i8 + j) | ((b & lomask) << 24) | (d[j] < 0 ? 0x80000000u : 0u);
+                    }
                 }
             }
         }
@@ -509,8 +519,10 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
             const int d = load_digit<DT>(dg, sg, i);
             if (d) {
                 const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
-                const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
-                tmp[pos] = (row + i) | ((b & lomask) << 24) | (d < 0 ? 0x80000000u : 0u);
+                if (b - blo < bcnt) {
+                    const uint32_t pos = atomicAdd(&lc[b >> lb], 1u);
+                    tmp[pos] = (row + i) | ((b & lomask) << 24) | (d < 0 ? 0x80000000u : 0u);
+                }
             }
         }
     }
@@ -524,7 +536,7 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
                                                                           const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
                                                                           uint32_t* __restrict__ tmp, uint32_t n, uint32_t bins, uint32_t lb,
                                                                           uint32_t slices, uint32_t slice_len, uint32_t win0, uint32_t wpg,
-                                                                          uint32_t idx_stride, uint32_t windows_per_job, uint32_t first_i0, uint32_t last_i1)
+                                                                          uint32_t idx_stride, uint32_t windows_per_job, uint32_t first_i0, uint32_t last_i1, uint32_t blo, uint32_t bcnt)
 {
     FRONT_PRIO();
     constexpr uint32_t TILE = SORT_THREADS * 8;
@@ -559,9 +571,11 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
             for (int j = 0; j < 8; j++) {
                 if (d[j] && i8 + j >= klo && i8 + j < khi) {
                     const uint32_t b = (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1);
-                    bn[j] = b >> lb;
-                    ent[j] = (row + i8 + j) | ((b & lomask) << 24) | (d[j] < 0 ? 0x80000000u : 0u);
-                    rk[j] = atomicAdd(&th[bn[j]], 1u);
+                    if (b - blo < bcnt) {
+                        bn[j] = b >> lb;
+                        ent[j] = (row + i8 + j) | ((b & lomask) << 24) | (d[j] < 0 ? 0x80000000u : 0u);
+                        rk[j] = atomicAdd(&th[bn[j]], 1u);
+                    }
                 }
             }
         }
@@ -864,7 +878,23 @@ __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kerne
                 store_raw(partials + (size_t)(b + t) * RAW_WORDS, acc);
                 b++;
                 next_end = after_next;
-                while (next_end <= e) { b++; next_end = gstart[b + 1]; } // skip empty buckets (rare at the sizes that matter)
+                if (next_end <= e) {
+                    // the next bucket is empty.  Not walked one by one: a bucket-range share has tens of thousands of empty buckets behind its
+                    // last entry, skewed digits leave long runs between a handful of full ones, and a dependent load per empty bucket
+                    // is ~90 ns (round 3 measurement: share 0 of 8 spent 5.4 ms here against 0.15 ms of additions).  Past the end of the
+                    // list sits the dummy bucket; otherwise the bucket that holds entry e is found as at the start of the chunk.
+                    if (e >= M) {
+                        b = total_buckets;
+                    } else {
+                        uint32_t l2 = b, h2 = total_buckets; // gstart[l2] <= e < gstart[h2]
+                        while (h2 - l2 > 1) {
+                            const uint32_t mid = (l2 + h2) >> 1;
+                            if (gstart[mid] <= e) l2 = mid; else h2 = mid;
+                        }
+                        b = l2;
+                    }
+                    next_end = gstart[b + 1];
+                }
                 after_next = gstart[min(b + 2, total_buckets + 1)];
             }
             acc.x = px;
@@ -954,12 +984,13 @@ __device__ __forceinline__ void wg_tree_sum(Xyzz& acc, uint32_t* sh, uint32_t T,
     }
 }
 __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
-                                                              uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
+                                                              uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t bucket_begin, uint32_t total_buckets,
                                                               uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logG)
 {
+    // buckets [bucket_begin, total_buckets): a bucket-range share merges (and later folds) its own buckets only
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t G = 1u << logG, b = t >> logG, j = t & (G - 1);
+    const uint32_t G = 1u << logG, b = bucket_begin + (t >> logG), j = t & (G - 1);
     if (b >= total_buckets) return; // whole groups leave together (groups are aligned inside a wave)
     const uint32_t s = gstart[b], e = gstart[b + 1];
     Xyzz acc;
@@ -1151,12 +1182,12 @@ __device__ __forceinline__ void quad_store8(uint32_t* dst8, const uint32_t (&w)[
 // ~ceil(count / Q) + logQ quad additions of ~1,250 instructions: at 2^20 (4 partials per bucket, Q = 1) 3 quad additions instead of
 // 3 full ones, at 2^16 (9.5 partials, Q = 4) 4 instead of 6.
 __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_quad_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
-                                                                   uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t total_buckets,
+                                                                   uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t bucket_begin, uint32_t total_buckets,
                                                                    uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logQ)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, l = t & 3, quad = t >> 2;
-    const uint32_t Q = 1u << logQ, b = quad >> logQ, j = quad & (Q - 1);
+    const uint32_t Q = 1u << logQ, b = bucket_begin + (quad >> logQ), j = quad & (Q - 1);
     if (b >= total_buckets) return; // whole bucket groups leave together (4 Q lanes, aligned inside a wave)
     const uint32_t s = gstart[b], e = gstart[b + 1];
     FqN acc = quad_zero();
@@ -1207,8 +1238,10 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
 }
 
 __global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_quad_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
-                                                                  uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words)
+                                                                  uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words, uint32_t r0, uint32_t rows)
 {
+    // rows [r0, r0 + rows) of the H x L bucket matrix (all of them, or a bucket-range share's): blockIdx.x < rows sums row r0 + blockIdx.x,
+    // the L blocks after them sum the columns over those rows.  R of the other rows is not written: the caller zeroed it (infinity).
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[(QFOLD_T / 64) * 4 * NL];
     const uint32_t g = blockIdx.y, t = threadIdx.x, nb = H * L, l = t & 3, quad = t >> 2;
@@ -1216,12 +1249,12 @@ __global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4,
         const uint32_t gid = (g * gridDim.x + blockIdx.x) * blockDim.x + t, all = gridDim.y * gridDim.x * blockDim.x;
         for (uint32_t i = gid; i < zero_words; i += all) zero_out[i] = 0;
     }
-    const bool row = blockIdx.x < H;
-    const uint32_t idx = row ? blockIdx.x : blockIdx.x - H, count = row ? L : H;
+    const bool row = blockIdx.x < rows;
+    const uint32_t idx = row ? r0 + blockIdx.x : blockIdx.x - rows, count = row ? L : rows;
     FqN acc = quad_zero();
     bool first = true;
     for (uint32_t e = quad; e < count; e += QFOLD_T / 4) { // quad-uniform trip count
-        const size_t b = row ? (size_t)idx * L + e : (size_t)e * L + idx;
+        const size_t b = row ? (size_t)idx * L + e : (size_t)(r0 + e) * L + idx;
         const FqN v = quad_load(buckets + ((size_t)g * nb + b) * 32, l);
         acc = first ? v : quad_add(acc, v, l);
         first = false;
@@ -1335,9 +1368,14 @@ static uint32_t acc_capacity_lanes()
 // chunk length of K4: one resident wave of workgroups covers the whole entry list (no tail wave), >= MIN_CHUNK entries per lane
 // (small MSMs are latency-bound: a lane's chain of `ch` dependent mixed additions is the critical path, ~5 us each)
 constexpr uint32_t MIN_CHUNK = 8;
+static uint32_t chunk_len_m(uint64_t m);
 static uint32_t chunk_len(size_t n, uint32_t nw)
 {
-    const uint64_t m = (uint64_t)n * nw;
+    return chunk_len_m((uint64_t)n * nw);
+}
+// m: expected number of entries of the sorted list
+static uint32_t chunk_len_m(const uint64_t m)
+{
     static int waves = 0; // BBGPU_ACC_WAVES: k > 1 cuts the list into k times as many (shorter) chunks -> k waves of workgroups (tuning experiments)
     if (!waves) {
         waves = 1;
@@ -1469,6 +1507,22 @@ int msm_issue_rows(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, siz
     return msm_issue_batch(S, d_srs, d_tab, tab_stride, tab_c, &d_scalars, 1, n, wb, we, st, want_timing, i0, i1);
 }
 
+// One of `share_count` BUCKET-RANGE shares of an MSM against window tables: every share reads all digits of all windows but keeps only
+// those whose bucket lies in its rows [H s / N, H (s + 1) / N) of the 2^hbits x 2^lbits bucket matrix, i.e. 1 / N of the mixed
+// additions AND 1 / N of the buckets to merge and fold -- the part of an MSM that a row-range share (above) repeats in full on every
+// rank.  The share's result is sum_{b in range} (b + 1) B_b (the bit-slice weights use the global bucket index), so the shares of
+// one MSM add up to it.  Uniform digits give equal shares; skewed ones (all scalars equal) put whole windows into one share.
+int msm_issue_buckets(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* d_scalars, size_t n,
+                      uint32_t share, uint32_t share_count, hipStream_t st, int want_timing)
+{
+    if (!d_tab || n == 0 || share_count == 0 || share >= share_count) return BBGPU_ERR_ARG;
+    const MsmPlan P = make_plan(n, tab_c);
+    const uint32_t H = 1u << P.hbits;
+    if (share_count > H) return BBGPU_ERR_ARG;
+    const uint32_t r0 = (uint32_t)((uint64_t)H * share / share_count), r1 = (uint32_t)((uint64_t)H * (share + 1) / share_count);
+    return msm_issue_batch(S, d_srs, d_tab, tab_stride, tab_c, &d_scalars, 1, n, 0, (int)P.W, st, want_timing, 0, 0xffffffffu, r0, r1);
+}
+
 // `jobs` MSMs of n scalars each over the SAME points as one pass through the pipeline (the prover's 3 / 1 / 3 / 2
 // commitments per round, prover.cpp:65-122,650-658): each job is a bucket set ("group") of the shared sort / accumulate / merge /
 // reduction kernels, so the batch costs one chain of launches and one chain of dependent group additions instead of `jobs`.
@@ -1489,7 +1543,7 @@ static int acc_ring_record(MsmSlot& S, hipStream_t st)
     return BBGPU_OK;
 }
 int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, size_t tab_stride, int tab_c, const uint64_t* const* d_scalars_v, int jobs,
-                    size_t n, int wb, int we, hipStream_t st, int want_timing, uint32_t row_i0, uint32_t row_i1)
+                    size_t n, int wb, int we, hipStream_t st, int want_timing, uint32_t row_i0, uint32_t row_i1, uint32_t brow0, uint32_t brow1)
 {
     MsmWorkspace& ws = S.ws;
     S.jobs = (uint32_t)jobs;
@@ -1513,6 +1567,13 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         set_error("batched MSM: 1..%d jobs, window tables and the full window range required", MSM_MAX_JOBS);
         return BBGPU_ERR_ARG;
     }
+    // a bucket-range share (msm_issue_buckets): rows [brow0, brow1) of the 2^hbits x 2^lbits bucket matrix over ALL windows and points --
+    // like a row-range share only with one shared bucket set (window tables), one job, and quad tail kernels
+    const uint32_t BH = 1u << P.hbits, BL = 1u << P.lbits;
+    if (brow1 > BH) brow1 = BH;
+    const bool bshare = brow0 != 0 || brow1 != BH;
+    if (bshare && (!table || jobs != 1 || brow0 >= brow1 || wb != 0 || we != (int)P.W || row_i0 != 0 || row_i1 != n)) return BBGPU_ERR_ARG;
+    const uint32_t blo = brow0 * BL, bcnt = (brow1 - brow0) * BL;
     const uint32_t nw1 = (uint32_t)(we - wb);     // windows processed per job
     const uint32_t nw = nw1 * (uint32_t)jobs;     // (job, window) pairs: what the entry count and the workspace scale with
     const uint32_t G = table ? (uint32_t)jobs : nw1; // bucket sets ("groups")
@@ -1525,6 +1586,14 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         while (sort_bins < want_bins && sort_lb > 3) { sort_lb--; sort_bins <<= 1; }
     }
     uint32_t slices = table ? std::max<uint32_t>(1, P.slices * nw1 / 2) : P.slices;
+    // a share of a few windows (a rank of an N-way split) would run pass A on a few dozen workgroups: rocprofv3 timeline of a 1/8 row share,
+    // 51 slices: histogram 12-46 us, staged scatter 36-79 us for 2 M entries (the whole 2^20 MSM: 52 us for 15.7 M).  At least ~200 slices
+    // where the points allow >= 2048 per slice and the histogram matrix of the workspace (nw * P.slices * 1024 words) holds them.
+    if (table && jobs == 1) {
+        const uint32_t by_cap = (uint32_t)(((uint64_t)nw * P.slices * 1024) / ((uint64_t)G * sort_bins));
+        const uint32_t want = std::min<uint32_t>(std::min<uint32_t>(208, (uint32_t)(n / 2048)), by_cap);
+        slices = std::max(slices, want);
+    }
     if (const char* e = getenv("BBGPU_SLICES")) slices = std::min<uint32_t>(std::max(1, atoi(e)), P.slices * nw1); // tuning knob
     const uint32_t slice_len = (uint32_t)((n + slices - 1) / slices);
     const uint32_t idx_stride = table ? (uint32_t)tab_stride : 0u;
@@ -1576,6 +1645,15 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         S.timed = true;
     }
 
+    if (bshare) {
+        static const bool quad_ok = [] { const char* e = getenv("BBGPU_QUAD_TAIL"); return !e || atoi(e) != 0; }();
+        if (!quad_ok) {
+            set_error("bucket-range shares need the quad tail kernels (BBGPU_QUAD_TAIL=0 is set)");
+            return BBGPU_ERR_STATE;
+        }
+        // row sums outside the share stay infinity (all zero): the bit-slice kernel reads every row.  First in the stream, far off the tail's critical path
+        HIPCHK(hipMemsetAsync(scratch, 0, (size_t)G * BH * 128, st));
+    }
     // K0
     ScalarSets sets{};
     for (int j = 0; j < jobs; j++) sets.p[j] = (const uint32_t*)d_scalars_v[j];
@@ -1584,36 +1662,39 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
-    if (wide) sortA_hist_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
-    else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1);
+    if (wide) sortA_hist_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
+    else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
     sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
     sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
     sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
     static const int staged = [] { const char* e = getenv("BBGPU_SORT_STAGED"); return e ? atoi(e) : 3; }(); // tuning knob: bit 0 pass B, bit 1 pass A
     if ((staged & 2) && (P.n & 7u) == 0) {
         if (wide) sortA_scatter_staged_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
-                                                                                  slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
+                                                                                  slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1, blo, bcnt);
         else sortA_scatter_staged_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
-                                                                            slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
+                                                                            slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1, blo, bcnt);
     } else
     if (wide) sortA_scatter_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
-                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
+                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1, blo, bcnt);
     else sortA_scatter_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
-                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1);
+                                                                   slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1, blo, bcnt);
     if (!(staged & 1)) sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     else if (table) sortB_staged_kernel<SORT_THREADS><<<dim3(sort_bins, G), SORT_THREADS, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     else sortB_staged_kernel<256><<<dim3(sort_bins, G), 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
     if (tm_acc) HIPCHK(hipEventRecord(ev[2], st));
     // K4 + K4m
     const uint32_t total_buckets = G * P.nb;
-    const uint32_t ch = chunk_len(n, nw);
+    // a bucket-range share expects its fraction of the entries (uniform digits); the grid below still covers the worst case
+    const uint64_t m_expected = bshare ? std::max<uint64_t>(1, (uint64_t)n * nw * bcnt / P.nb) : (uint64_t)n * nw;
+    const uint32_t merge_buckets = bshare ? bcnt : total_buckets; // buckets the merge and the folds visit
+    const uint32_t ch = bshare ? chunk_len_m(m_expected) : chunk_len(n, nw);
     // merge: 2^logG lanes per bucket, sized for the expected number of partials per bucket (~ entries / (buckets * ch) + 1);
     // a bucket cut into more than 8 partials per lane of its group is queued for the workgroup-per-bucket kernel
     // -- but no wider than what fills the chip once (~2^16 lanes): beyond that the extra lanes only add issue work
-    const uint32_t avg_partials = (uint32_t)(((uint64_t)n * nw) / ((uint64_t)G * P.nb * ch)) + 1;
+    const uint32_t avg_partials = (uint32_t)(m_expected / ((uint64_t)merge_buckets * ch)) + 1;
     uint32_t logG = 0;
     static const uint32_t lanes_log = [] { const char* e = getenv("BBGPU_MERGE_LANES_LOG"); return e ? (uint32_t)std::min(20, std::max(14, atoi(e))) : 16u; }(); // tuning knob
-    while ((1u << logG) < avg_partials && logG < 6 && ((uint64_t)G * P.nb << (logG + 1)) <= ((uint64_t)1 << lanes_log)) logG++;
+    while ((1u << logG) < avg_partials && logG < 6 && ((uint64_t)merge_buckets << (logG + 1)) <= ((uint64_t)1 << lanes_log)) logG++;
     const uint32_t merge_light = std::max(6u, 8u << logG);
     const uint32_t max_chunks = (uint32_t)(((uint64_t)n * nw + ch - 1) / ch);
     // An MSM is a chain of dependent launches: its three helper launches -- two fills and the device-to-host copy, ~5 us each -- are folded
@@ -1640,13 +1721,13 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     if (quad_tail && (quad_merge > 1 || (quad_merge == 1 && (uint64_t)n * nw <= quad_merge_max_entries))) {
         // quads per bucket: about half the expected number of partials, within one resident wave of tail workgroups (~2^18 lanes)
         uint32_t logQ = 0;
-        while ((2u << logQ) < avg_partials && logQ < 4 && ((uint64_t)total_buckets << (logQ + 3)) <= ((uint64_t)1 << 17)) logQ++;
+        while ((2u << logQ) < avg_partials && logQ < 4 && ((uint64_t)merge_buckets << (logQ + 3)) <= ((uint64_t)1 << 17)) logQ++;
         if (quad_merge > 1) logQ = std::min(4, quad_merge - 2);
-        msm_merge_quad_kernel<<<(uint32_t)((((uint64_t)total_buckets << (logQ + 2)) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, total_buckets, ch,
+        msm_merge_quad_kernel<<<(uint32_t)((((uint64_t)merge_buckets << (logQ + 2)) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, blo, blo + merge_buckets, ch,
                                                                                                                                   std::max(32u, 8u << logQ), logQ);
     } else
-    msm_merge_kernel<<<(uint32_t)((((uint64_t)total_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
-                                                                                                                     total_buckets, ch, merge_light, logG);
+    msm_merge_kernel<<<(uint32_t)((((uint64_t)merge_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
+                                                                                                                     blo, blo + merge_buckets, ch, merge_light, logG);
     msm_merge_heavy_kernel<<<256, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
     if (tm) HIPCHK(hipEventRecord(ev[4], st));
 
@@ -1660,7 +1741,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         uint32_t* Cc = scratch + (size_t)G * H * 32;
         uint32_t* dest = fold ? (uint32_t*)ws.h_out : texp; // pinned host memory is device-accessible under the same pointer
         const uint32_t zero_words = G * 64 * 32;
-        if (quad_tail) msm_rowcol_quad_kernel<<<dim3(H + L, G), QFOLD_T, 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
+        if (quad_tail) msm_rowcol_quad_kernel<<<dim3((bshare ? brow1 - brow0 : H) + L, G), QFOLD_T, 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words, bshare ? brow0 : 0u,
+                                                                                                   bshare ? brow1 - brow0 : H);
         else msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
         if (tm) HIPCHK(hipEventRecord(ev[5], st));
         if (!fold) HIPCHK(hipMemsetAsync(texp, 0, (size_t)G * 64 * 128, st)); // unused slots = infinity (zz = 0)

@@ -398,7 +398,7 @@ def main():
     single = (rank == 0 and world == 1)
     cpu_leg = single and not args.no_cpu_baseline  # the CPU reference is timed at N = 1 only
     host_legs = single and not args.no_boundary   # boundary-inclusive legs need the host copy of the point table
-    if world > 1 and not args.no_window_tables:
+    if world > 1 and not args.no_window_tables and args.shard != "buckets":
         G.set_table_share(rank, world)  # this rank's 1/N of the (window, point) rows touches ceil(W / N) + 1 digit windows: only those are built and kept
     torch.cuda.synchronize()
     t_srs0 = time.perf_counter()
@@ -417,11 +417,14 @@ def main():
 
     # with window tables (one shared bucket set) the W * n (window, point) pairs split at ANY row, so every rank takes exactly 1/N of them
     # even when N does not divide W (15 windows of 17 bits at 2^20); without tables the split follows whole windows
-    wb_tab, we_tab = (W * rank // world, -(-W * (rank + 1) // world)) if world > 1 else (0, W)  # digit windows whose tables this rank keeps
-    by_rows = world > 1 and G.srs_has_window_tables(srs)
+    wb_tab, we_tab = (W * rank // world, -(-W * (rank + 1) // world)) if (world > 1 and args.shard != "buckets") else (0, W)  # digit windows whose tables this rank keeps
+    by_buckets = world > 1 and args.shard == "buckets" and G.srs_has_window_tables(srs)  # every rank over all windows and points, 1 / N of the bucket range
+    by_rows = world > 1 and args.shard == "rows" and G.srs_has_window_tables(srs)
     rows = (W * n * rank // world, W * n * (rank + 1) // world)
 
     def issue():
+        if by_buckets:
+            return G.msm_device_buckets_async(srs, d_scalars.data_ptr(), n, rank, world)
         if by_rows:
             return G.msm_device_rows_async(srs, d_scalars.data_ptr(), n, rows[0], rows[1])
         return G.msm_device_async(srs, d_scalars.data_ptr(), n, 0, wb, we) if we > wb else None
@@ -441,12 +444,16 @@ def main():
         return part
 
     exchange = PartialSumExchange(G, world, xdev) if world > 1 else None
+    # shares in flight: two at N <= 2 (the full MSM measured worse with more: one more front / tail competing with the accumulation), four from
+    # N = 4 on, where a share is a chain of short launches (tools/share_ab.py, a middle 1/8 row share: 0.362 / 0.248 / 0.268 / 0.226 ms per
+    # step with 1 / 2 / 3 / 4 in flight; 1/4: 0.571 / 0.364 / 0.431 / 0.358)
+    depth = 4 if world >= 4 else 2
 
     def run_steps(k):
         """k complete MSMs; step i+1 is enqueued before step i is collected (two-slot pipeline of the library), so the
         bucket-reduction tail + host finish of one step overlap the sort/accumulate of the next; with N > 1 the exchange of
         step i is in flight while step i+1 is collected (barretenberg_amd/sharding.py)"""
-        out = pipelined_steps(k, issue, collect, exchange)
+        out = pipelined_steps(k, issue, collect, exchange, depth=depth)
         return out[-1] if out else None
 
     def finish(ticket):
@@ -498,7 +505,10 @@ def main():
     stage = np.zeros(7)
     reps = 5
     for _ in range(reps):
-        if by_rows:
+        if by_buckets:
+            G.msm_wait(G.msm_device_buckets_async(srs, d_scalars.data_ptr(), n, rank, world))
+            stage += np.array(G.last_timing()[:7])
+        elif by_rows:
             G.msm_wait(G.msm_device_rows_async(srs, d_scalars.data_ptr(), n, rows[0], rows[1]))
             stage += np.array(G.last_timing()[:7])
         elif we > wb:
@@ -629,7 +639,7 @@ def main():
                     rocprof_spacing_ms = float(m.group(1))
                     rocprof_frac = alg_bytes / (rocprof_spacing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 break
-        share_adds = (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation
+        share_adds = (W * n // world) if by_buckets else (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation (expected, for bucket shares)
         # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition (round-3 loop: 2,142 instructions in the hot
         # path + ~85 in the bucket-start block that ~1 trip in 4 runs) = 738 v_mad_u64_u32 with two VGPR factors + 729 with an SGPR factor
         # + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 194 v_and_b32 + ~275 other VALU, priced at the measured chip-wide issue rates of
@@ -660,7 +670,7 @@ def main():
                                           "srs_setup_ms": srs_setup_ms, "srs_setup_what": "bbgpu_srs_generate: points + window tables" + (" + host copy of the point table" if table is not None else ""),
                                           "srs_table_bytes": int(min(we_tab - wb_tab, W) * n * 64) if not args.no_window_tables and W * n <= (1 << 24) else 0, "srs_points_bytes": n * 64,
                                           "ntt_table_bytes": int(4 * n * 32) if n <= (1 << 22) else None},
-                       "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
+                       "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by bucket range (all windows and points, 1 / N of the buckets each)" if by_buckets else "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
                        "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
                          "merge": float(stage[4]), "bucket_folds": float(stage[5]), "slices_collect": float(stage[6]),

@@ -167,6 +167,13 @@ int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_s
  * Collected with bbgpu_msm_g1_wait like any other ticket; the partial sums of a complete split add up to the MSM (bbgpu_g1_sum). */
 int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, uint64_t row_begin, uint64_t row_end,
                                    void* hip_stream);
+/* The other way to split one MSM over N ranks (against window tables): share s of N keeps the digits whose BUCKET falls into its 1 / N of
+ * the bucket range -- all windows, all points.  Every share then holds 1 / N of the mixed additions AND 1 / N of the buckets to merge
+ * and fold (a row share repeats that tail in full on every rank), at the price of every rank scanning all digits and keeping all window
+ * tables (no bbgpu_set_table_share).  Balanced for uniform digits; the partial sums of shares 0 .. N-1 add up to the MSM (bbgpu_g1_sum).
+ * N <= the rows of the bucket matrix (256 at 17-bit windows).  Replaces the slicing of scalar_multiplication.cpp:703-738 (there: ranges of
+ * POINTS per thread, summed at the end) at the multi-GPU level. */
+int bbgpu_msm_g1_device_buckets_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int share, int share_count, void* hip_stream);
 int bbgpu_srs_has_window_tables(int srs_handle); /* 1 / 0, < 0: unknown handle */
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12]);
 /* Whole-batch entry (the prover commits 3 / 1 / 3 / 2 polynomials per round over the same SRS,

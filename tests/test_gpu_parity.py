@@ -481,6 +481,70 @@ def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
         for a, b in zip(cuts[:-1], cuts[1:]):  # two in flight, like the ranks' pipelines
             parts.append(gpu.msm_wait(gpu.msm_device_rows_async(h, d_sc.data_ptr(), n, a, b)))
         _check(gpu.g1_sum(np.stack(parts)), case)
+        # ... and eight (and three: 256 rows of the bucket matrix do not divide by 3) BUCKET-range shares: every share over all windows
+        # and points, 1 / N of the buckets each (round 3: the split whose per-rank tail shrinks with N)
+        for N in (8, 3):
+            tickets, parts = [], []
+            for r in range(N):  # two in flight
+                tickets.append(gpu.msm_device_buckets_async(h, d_sc.data_ptr(), n, r, N))
+                if len(tickets) == 2:
+                    parts.append(gpu.msm_wait(tickets.pop(0)))
+            parts += [gpu.msm_wait(t) for t in tickets]
+            _check(gpu.g1_sum(np.stack(parts)), case)
+
+
+def test_msm_bucket_range_shares(gpu, oracle, msm_small, golden):
+    """bucket-range shares (bbgpu_msm_g1_device_buckets_async) against the oracle: sizes on both sides of the 16-byte digit loads
+    (n % 8 != 0 takes the one-digit-per-load sort kernels), share counts that do and do not divide the bucket matrix's rows, uniform
+    and skewed scalars (all equal: whole windows fall into ONE share, the others see empty lists; {0, 1, -1}; small values) -- the
+    shares of one MSM must add up to the oracle's point, and a single share of one must equal the MSM itself"""
+    import torch
+    g, srs, table, scalars = msm_small
+    one = oracle.const(FR, "one")
+    minus_one = oracle.neg(FR, one)
+    rng = np.random.default_rng(11)
+    for n in (1 << 14, 5000, 1029):
+        tab = aligned_copy(table[:2 * n])
+        h = gpu.srs_register(tab)
+        if not gpu.srs_has_window_tables(h):  # the suite's second pass (bbgpu_set_precompute(0)): shares of the bucket range need the shared bucket set
+            from barretenberg_amd import BbGpuError
+            d0 = torch.from_numpy(aligned_copy(scalars[:n]).view(np.int64)).cuda()
+            with pytest.raises(BbGpuError):
+                gpu.msm_device_buckets_async(h, d0.data_ptr(), n, 0, 2)
+            gpu.srs_release(h)
+            continue
+        sets = {
+            "uniform": scalars[:n],
+            "all equal": np.tile(scalars[7], (n, 1)),
+            "0/1/-1": np.stack([(np.zeros(4, dtype=np.uint64), one, minus_one)[i] for i in rng.integers(0, 3, n)]),
+            "small": np.stack([oracle.to_mont(FR, np.array([int(v), 0, 0, 0], dtype=np.uint64)) for v in rng.integers(0, 200, n)]),
+        }
+        for name, sc in sets.items():
+            sc = aligned_copy(sc)
+            want = oracle.msm_affine(sc, tab, n)
+            d = torch.from_numpy(sc.view(np.int64)).cuda()
+            for N in (1, 2, 5, 8):
+                parts = [gpu.msm_wait(gpu.msm_device_buckets_async(h, d.data_ptr(), n, r, N)) for r in range(N)]
+                got = gpu.g1_sum(np.stack(parts))
+                assert np.array_equal(got[:8], want[:8]), (n, name, N)
+        gpu.srs_release(h)
+    # argument checks: share out of range, more shares than rows of the bucket matrix, a table without window tables
+    from barretenberg_amd import BbGpuError
+    tab = aligned_copy(table[:2 * 2048])
+    h = gpu.srs_register(tab)
+    d = torch.from_numpy(aligned_copy(scalars[:2048]).view(np.int64)).cuda()
+    for share, count in ((2, 2), (-1, 2), (0, 0), (0, 100000)):
+        with pytest.raises(BbGpuError):
+            gpu.msm_device_buckets_async(h, d.data_ptr(), 2048, share, count)
+    gpu.srs_release(h)
+    gpu.set_precompute(False)
+    try:
+        h = gpu.srs_register(tab)
+        with pytest.raises(BbGpuError):
+            gpu.msm_device_buckets_async(h, d.data_ptr(), 2048, 0, 2)
+        gpu.srs_release(h)
+    finally:
+        gpu.set_precompute(True)
 
 
 def test_msm_around_the_table_mode_switch(gpu, oracle, golden):

@@ -17,7 +17,7 @@ sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64); sc[:, 3] &= np.uint
 d = torch.from_numpy(sc.view(np.int64)).cuda()
 W = G.srs_num_windows(srs, n)
 base = None
-report = {"what": "one rank's share of a 2^20-point MSM on one MI355X, ms per step (median of 5 x 24 steps), no exchange step", "windows": W, "row_range": {}, "whole_windows": {}}
+report = {"what": "one rank's share of a 2^20-point MSM on one MI355X, ms per step (median of 5 x 24 steps), no exchange step", "windows": W, "bucket_range": {}, "row_range": {}, "whole_windows": {}}
 
 
 def timed(run):
@@ -58,6 +58,26 @@ for N in (1, 2, 4, 8):
         if depth == 2:
             report["row_range"]["N=%d" % N]["speedup_vs_N1"] = base / dt
         print("N=%d (%.3f windows per rank), %d in flight: %.3f ms/step%s" % (N, W / N, depth, dt * 1e3, "  = %.2fx of N=1" % (base / dt) if base else ""), flush=True)
+
+# bucket-range shares (round 3): share 0 of N over all windows and points -- 1 / N of the additions and 1 / N of the buckets to merge and fold
+bbase = None
+for N in (1, 2, 4, 8):
+    for depth in (1, 2, 3, 4):
+        def run(k):
+            infl = []
+            for _ in range(k):
+                infl.append(G.msm_device_buckets_async(srs, d.data_ptr(), n, N // 2, N))  # a middle share
+                if len(infl) == depth:
+                    G.msm_wait(infl.pop(0))
+            while infl:
+                G.msm_wait(infl.pop(0))
+        dt = timed(run)
+        if bbase is None and depth == 2:
+            bbase = dt
+        report["bucket_range"].setdefault("N=%d" % N, {})["ms_per_step_%d_in_flight" % depth] = dt * 1e3
+        if depth == 2:
+            report["bucket_range"]["N=%d" % N]["speedup_vs_N1"] = bbase / dt
+        print("buckets N=%d, %d in flight: %.3f ms/step%s" % (N, depth, dt * 1e3, "  = %.2fx of N=1" % (bbase / dt) if bbase else ""), flush=True)
 
 # host-side cost of one step at the smallest share: time inside the two calls
 rows8 = W * n // 8
