@@ -360,6 +360,41 @@ template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_ke
 constexpr int SORT_THREADS = 1024;
 constexpr uint32_t SORT_MAX_LB = 7;
 
+// LDS counter increments for keys that may be heavily duplicated inside a wave.  With uniform digits the 64 lanes of a wave hit ~60 different
+// counters and the plain LDS atomic is the right tool; with skewed scalars (every scalar equal, 0 / 1 / -1 witnesses: what real circuits hold) all
+// lanes hit ONE counter, the LDS serialises them, and the sort of a 2^20-point MSM went from 0.13 to 2.2 ms (tools/skewed_stages.py).
+// wave_keys_heavy(): one test per lane trip (8 entries), on the trip's first entry -- do at least a quarter of the lanes that have one share
+// the first such lane's key?  (Wave-uniform among the lanes that call it.)  Only then lds_inc_dedup() peels up to four distinct keys
+// per entry slot -- one atomic of the group's size by its first lane, the others take consecutive ranks -- and lets whatever is left fall back
+// to the plain atomic.  lds_inc_dedup is called by the lanes that have an entry (divergent code: its ballots see the active lanes only) and
+// returns the counter value before this lane's increment, like atomicAdd.
+__device__ __forceinline__ bool wave_keys_heavy(bool valid, uint32_t key)
+{
+    const uint64_t vm = __ballot(valid);
+    if (!vm) return false;
+    const uint32_t k0 = __builtin_amdgcn_readlane(key, __ffsll((unsigned long long)vm) - 1);
+    return 4 * __popcll(__ballot(valid && key == k0)) >= __popcll(vm);
+}
+__device__ __forceinline__ uint32_t lds_inc_dedup(uint32_t* ctr, uint32_t key, bool heavy)
+{
+    if (!heavy) return atomicAdd(&ctr[key], 1u); // wave-uniform
+    const uint32_t lane = __lane_id();
+    uint64_t todo = __ballot(1);
+    uint32_t res = 0;
+    for (int it = 0; it < 4 && todo; it++) { // wave-uniform loop
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t kk = __builtin_amdgcn_readlane(key, leader);
+        const uint64_t m = __ballot(key == kk) & todo;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&ctr[kk], (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if ((m >> lane) & 1ull) res = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    if ((todo >> lane) & 1ull) res = atomicAdd(&ctr[key], 1u);
+    return res;
+}
+
 // A "group" is a set of `wpg` consecutive windows that share one bucket set: 1 window per group normally, all windows of
 // the call in one group when the SRS carries pre-shifted window tables (the window weight is then baked into the point).
 template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_hist_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, uint32_t* __restrict__ histA, uint32_t n,
@@ -382,11 +417,12 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
             const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
             int d[8];
             load_digits8<DT>(digits + (size_t)(win0 + wl * wpg + k) * n, signs + (size_t)(win0 + wl * wpg + k) * s64, i8, d);
+            const bool heavy = wave_keys_heavy(d[0] != 0, (uint32_t)((d[0] < 0 ? -d[0] : d[0]) - 1) >> lb); // among the lanes still in the loop
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 if (d[j] && i8 + j >= klo && i8 + j < khi) {
                     const uint32_t b = (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1);
-                    if (b - blo < bcnt) atomicAdd(&lh[b >> lb], 1u);
+                    if (b - blo < bcnt) (void)lds_inc_dedup(lh, b >> lb, heavy);
                 }
         }
     } else {
@@ -567,6 +603,7 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
             const uint32_t klo = (k == 0) ? max(lo, first_i0) : lo, khi = (k + 1 == wpg) ? min(hi, last_i1) : hi;
             int d[8];
             load_digits8<DT>(digits + (size_t)wabs * n, signs + (size_t)wabs * s64, i8, d);
+            const bool heavy = wave_keys_heavy(d[0] != 0, (uint32_t)((d[0] < 0 ? -d[0] : d[0]) - 1) >> lb);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 if (d[j] && i8 + j >= klo && i8 + j < khi) {
@@ -574,7 +611,7 @@ template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute_
                     if (b - blo < bcnt) {
                         bn[j] = b >> lb;
                         ent[j] = (row + i8 + j) | ((b & lomask) << 24) | (d[j] < 0 ? 0x80000000u : 0u);
-                        rk[j] = atomicAdd(&th[bn[j]], 1u);
+                        rk[j] = lds_inc_dedup(th, bn[j], heavy);
                     }
                 }
             }
@@ -703,9 +740,10 @@ template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_staged_k
             const uint32_t e = e0 + k * THREADS;
             v[k] = e < end ? tmp[e] : 0u;
         }
+        const bool heavy = wave_keys_heavy(e0 < end, (v[0] >> 24) & 0x7f);
 #pragma unroll
         for (int k = 0; k < UB; k++)
-            if (e0 + k * THREADS < end) atomicAdd(&cnt[(v[k] >> 24) & 0x7f], 1u);
+            if (e0 + k * THREADS < end) (void)lds_inc_dedup(cnt, (v[k] >> 24) & 0x7f, heavy);
     }
     __syncthreads();
     if (t < 64) { // exclusive scan of the <= 128 counters by one wave, two counters per lane
@@ -730,9 +768,12 @@ template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_staged_k
             const uint32_t e = base + k * THREADS + t;
             v[k] = e < end ? tmp[e] : 0u;
         }
+        const bool heavy = wave_keys_heavy(base + t < end, (v[0] >> 24) & 0x7f);
 #pragma unroll
-        for (int k = 0; k < UB; k++)
-            rk[k] = (base + k * THREADS + t < end) ? atomicAdd(&cnt[(v[k] >> 24) & 0x7f], 1u) : 0u;
+        for (int k = 0; k < UB; k++) {
+            rk[k] = 0u;
+            if (base + k * THREADS + t < end) rk[k] = lds_inc_dedup(cnt, (v[k] >> 24) & 0x7f, heavy);
+        }
         __syncthreads();
         if (t < 64) {
             const uint32_t a = cnt[2 * t], b2 = cnt[2 * t + 1], sum = a + b2;

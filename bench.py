@@ -532,7 +532,7 @@ def main():
 
     # ---- single-GPU extras (rank 0, N = 1): 4 * 2^20 transforms, config 1, the boundary-inclusive numbers ---------------------------
     ntt22 = ntt22_in = ntt22_out = None
-    config1 = boundary = None
+    config1 = boundary = skewed = None
     table16 = res16 = None
     if host_legs:
         n22 = 1 << 22
@@ -549,8 +549,9 @@ def main():
         del d22
         # config 1 (bench_barretenberg.cpp:308-332): 2^16 points of the same SRS and the first 2^16 scalars
         m = 1 << 16
-        table16 = np.ascontiguousarray(table[:2 * m])
+        table16 = table[:2 * m].copy()  # its OWN memory: registering a view of the big table would hand back (and later release) the big table's handle
         h16 = G.srs_register(table16)
+        assert h16 != srs
         for _ in range(20):  # out of the post-idle ramp first, like the main leg (tools/step_gap.py)
             G.msm_device(h16, d_scalars.data_ptr(), m)
         lat16, lat16_min = median_ms(lambda: G.msm_device(h16, d_scalars.data_ptr(), m), 10, 3)
@@ -568,6 +569,24 @@ def main():
         config1 = {"workload": "2^16-point G1 MSM (BASELINE config 1 on the GPU), inputs resident", "latency_ms": lat16, "latency_ms_min": lat16_min,
                    "ms_per_msm_two_in_flight": pipe16 / 10, "points_per_s": m / (pipe16 / 10 * 1e-3)}
         G.srs_release(h16)
+        # skewed scalars at the full size (what real witnesses look like; parity of exactly these vectors against the reference's points:
+        # tests/test_gpu_parity.py::test_msm_skewed_scalars_full_size): latency and two-in-flight step next to the uniform figures
+        skewed = {"note": "2^20 points, inputs resident; latency = one MSM at a time (median of 5 after 2), step = two in flight (10 steps); uniform scalars: latency_ms_single_msm / ms_per_step"}
+        for kind in SKEWED_KINDS:
+            d_sk = torch.from_numpy(np.ascontiguousarray(skewed_scalars(kind, n)).view(np.int64)).to(dev)
+            lat_sk, _ = median_ms(lambda: G.msm_device(srs, d_sk.data_ptr(), n), 5, 2)
+
+            def two_sk(k=10):
+                infl = []
+                for _ in range(k):
+                    infl.append(G.msm_device_async(srs, d_sk.data_ptr(), n))
+                    if len(infl) == 2:
+                        G.msm_wait(infl.pop(0))
+                while infl:
+                    G.msm_wait(infl.pop(0))
+            step_sk, _ = median_ms(two_sk, 3, 1)
+            skewed[kind] = {"latency_ms": lat_sk, "ms_per_step": step_sk / 10}
+            del d_sk
         # boundary-inclusive: wall-clock around the drop-in calls with pageable host buffers -- H2D of the scalars (SRS
         # resident, as in the prover), H2D + D2H of the coefficients; median of 10 after 3; different scalars every call
         hs = [scalars, np.roll(scalars, 1, axis=0).copy(), np.roll(scalars, 2, axis=0).copy()]
@@ -696,6 +715,7 @@ def main():
                                 "roofline": ntt_roofline(1 << 22, ntt22["fft"]["device_ms"], None)}
         if config1 is not None:
             line["config1_2e16"] = config1
+            line["skewed_2e20"] = skewed
         if boundary is not None:
             line["boundary"] = boundary
         if sharded_ok is not None:
