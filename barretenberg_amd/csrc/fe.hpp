@@ -64,6 +64,15 @@ template <class F> using FeN = Fe<F, 1, 12>;  // the storage type of kernels: ti
 template <class F, int V> struct FeE : Fe<F, 1, V> {
     BB_HD FeE() {}
 };
+// mul / sqr / mul_add results and unpack() have exact limbs by construction (every limb but the top one is masked to 29 bits, the top one is
+// below 2^29 because the value is below 2^261): say so where a subtraction can use it.  For those sources ONLY.
+template <class F, int V> BB_HD FeE<F, V> exact_limbs(const Fe<F, 1, V>& product_or_unpacked)
+{
+    FeE<F, V> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.d[i] = product_or_unpacked.d[i];
+    return r;
+}
 
 // ---- constants --------------------------------------------------------------------------------------------------
 struct Limbs9 {

@@ -33,6 +33,12 @@ namespace bbgpu {
 using Fr = FrP;
 constexpr int NTT_VMAX = 48;                 // lazy value bound inside one pass: 6 + 3 * 12 stages + slack
 using FrL = Fe<Fr, 1, NTT_VMAX>;             // LDS-resident element
+// The fused pass keeps LAZIER limbs in LDS (round 3): up to 4 U.  A radix-2^2 group then needs two renormalisations instead of four -- the
+// element in the x0 role (never multiplied inside the group) when it is loaded, and the one output whose bound would reach 5 U -- because
+// the other three inputs go through the multiplier (L1 L2 <= 6) and differences with a PRODUCT as subtrahend need the small borrow-proofing
+// offset (fe.hpp FeE): 24 instructions each, 12 of them saved per group and pass at log_s = 10 (-4.6 % of the pass's VALU instructions).
+constexpr int NTT_LDSL = 4;
+using FrS = Fe<Fr, NTT_LDSL, NTT_VMAX>;
 constexpr int NTT_MAX_LOG2N = 28;            // two-adicity of r - 1 (fr.hpp:60-63): the largest domain the reference has a root for
 constexpr int NTT_MAX_LOG_SUB = 11;          // sub-transform up to 2048 points (72 KiB of LDS)
 constexpr int NTT_LDS_ELEMS = 2048;          // elements of LDS per workgroup (9 words each = 72 KiB) -> 2 WG / CU
@@ -297,12 +303,13 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
 //      through twist / scaling / canonicalisation straight to memory.
 // Two barriers and two LDS round trips fewer per pass, and the memory phases are no longer pure waiting (all workgroups of a 2^20
 // transform run in lockstep -- one resident wave of them holds the whole vector -- so nothing else could overlap them).
-template <int FLAGS> __device__ __forceinline__ void ntt_finish_store(const NttPassArgs& A, const FrL& x, uint32_t k, uint32_t b)
+template <int FLAGS, int L> __device__ __forceinline__ void ntt_finish_store(const NttPassArgs& A, const Fe<Fr, L, NTT_VMAX>& x, uint32_t k, uint32_t b)
 {
+    static_assert(L <= 6, "the twist / scaling product takes limbs up to 6 U");
     const size_t gidx = (size_t)k * A.out_sa + (size_t)b * A.out_sb;
     uint32_t w[8];
     if ((A.debug_skip & 2) != 0) {
-        pack(assume_bound<1, 2>(x), w);
+        pack(assume_bound<L, 2>(x), w);
     } else if constexpr ((FLAGS & 2) && (FLAGS & 32)) {
         // one multiplication per element: the twist factor comes from a table as large as the vector, read exactly like the output is written
         uint32_t tw8[8];
@@ -335,6 +342,30 @@ template <int FLAGS> __device__ __forceinline__ void ntt_finish_store(const NttP
         to_canonical(r, w);
     }
     store8(A.out + (size_t)blockIdx.y * A.out_bstride + 8 * gidx, w);
+}
+
+// One radix-2^2 group (stages s, s + 1) on LDS-lazy inputs: x0 renormalised (nobody multiplies it), everything else straight into the
+// multiplier; outputs at 3 / 4 / 4 / 5 U.  Limb bounds are checked by the types (mul's static_assert), value bounds as in the rest of the pass.
+struct Radix4Out {
+    Fe<Fr, 3, NTT_VMAX> y0;
+    Fe<Fr, 4, NTT_VMAX> y1, y2;
+    Fe<Fr, 5, NTT_VMAX> y3;
+};
+__device__ __forceinline__ Radix4Out radix4_lazy(const FrS& x0, const FrS& x1, const FrS& x2, const FrS& x3, const FeT<Fr>& w1, const FeT<Fr>& w2a, const FeT<Fr>& w2b)
+{
+    const FrL x0w = weak(x0);
+    const auto t1 = exact_limbs(mul(w1, x1)), t3 = exact_limbs(mul(w1, x3)); // < 3p
+    const auto a0 = add(x0w, t1);                                               // 2 U
+    const auto a1 = sub(x0w, t1);                                               // 3 U
+    const auto a2 = add(x2, t3);                                                // 5 U
+    const auto a3 = sub(x2, t3);                                                // 6 U: the multiplier's limit
+    const auto u2 = exact_limbs(mul(w2a, a2)), u3 = exact_limbs(mul(w2b, a3));
+    Radix4Out o;
+    o.y0 = assume_bound<3, NTT_VMAX>(add(a0, u2));
+    o.y2 = assume_bound<4, NTT_VMAX>(sub(a0, u2));
+    o.y1 = assume_bound<4, NTT_VMAX>(add(a1, u3));
+    o.y3 = assume_bound<5, NTT_VMAX>(sub(a1, u3));
+    return o;
 }
 
 #ifndef NTT_OCC_ATTR
@@ -371,21 +402,21 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
         }
         // row t + j S/4 sits at bit-reversed index 4 bitrev(t) + bitrev2(j): the group of LDS indices 4q .. 4q + 3 is rows (0, 2, 1, 3)
         const uint32_t q = bitrev(t, A.log_s - 2), cb = c * S;
-        const In &z0 = x[0], &z1 = x[2], &z2 = x[1], &z3 = x[3];
-        FrL y0, y1, y2, y3;
+        const auto z0 = exact_limbs(x[0]), z1 = exact_limbs(x[2]), z2 = exact_limbs(x[1]), z3 = exact_limbs(x[3]); // unpack() / products: exact limbs
+        FrS y0, y1, y2, y3;
         if (A.debug_skip & 1) {
             y0 = z0; y1 = z1; y2 = z2; y3 = z3;
         } else {
-            const auto a0 = add(z0, z1);
-            const auto a1 = sub(z0, z1);
-            const auto a2 = add(z2, z3);
-            const auto a3 = sub(z2, z3);
-            const FeT<Fr> w4 = load_tw(A.tw_sub, 1u << (A.log_s - 2)); // w_S^(S/4)
-            const auto u3 = mul(w4, a3);                               // < 3p
-            y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, a2)));
-            y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, a2)));
-            y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
-            y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
+            const auto a0 = add(z0, z1);                                   // 2 U
+            const auto a1 = sub(z0, z1);                                   // 3 U
+            const auto a2 = add(z2, z3);                                   // 2 U
+            const auto a3 = sub(z2, z3);                                   // 3 U
+            const FeT<Fr> w4 = load_tw(A.tw_sub, 1u << (A.log_s - 2));     // w_S^(S/4)
+            const auto u3 = exact_limbs(mul(w4, a3));                      // < 3p
+            y0 = assume_bound<4, NTT_VMAX>(add(a0, a2));                   // 4 U: stays lazy
+            y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, a2)));             // 6 U -> renormalised
+            y1 = assume_bound<4, NTT_VMAX>(add(a1, u3));                   // 4 U
+            y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));             // 5 U -> renormalised
         }
         const uint32_t e0 = cb + lds_pos(4 * q), e1 = cb + lds_pos(4 * q + 1), e2 = cb + lds_pos(4 * q + 2), e3 = cb + lds_pos(4 * q + 3);
 #pragma unroll
@@ -409,7 +440,7 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
             const uint32_t j = q & (m - 1);
             const uint32_t i0 = ((q >> s) << (s + 2)) | j, cb = c * S;
             const uint32_t e0 = cb + lds_pos(i0), e1 = cb + lds_pos(i0 + m), e2 = cb + lds_pos(i0 + 2 * m), e3 = cb + lds_pos(i0 + 3 * m);
-            FrL x0, x1, x2, x3;
+            FrS x0, x1, x2, x3;
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 x0.d[l] = lds[l * E + e0];
@@ -418,23 +449,15 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
                 x3.d[l] = lds[l * E + e3];
             }
             const FeT<Fr> w1 = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
-            const auto t1 = mul(w1, x1), t3 = mul(w1, x3); // < 3p
-            const auto a0 = add(x0, t1);
-            const auto a1 = sub(x0, t1);
-            const auto a2 = add(x2, t3);
-            const auto a3 = sub(x2, t3);
             const FeT<Fr> w2a = load_tw(A.tw_sub, j << (A.log_s - 2 - s));
             const FeT<Fr> w2b = load_tw(A.tw_sub, (j + m) << (A.log_s - 2 - s));
-            const auto u2 = mul(w2a, a2), u3 = mul(w2b, a3); // < 3p
-            const FrL y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, u2)));
-            const FrL y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, u2)));
-            const FrL y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
-            const FrL y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
+            const Radix4Out o = radix4_lazy(x0, x1, x2, x3, w1, w2a, w2b);
+            const FrL y3 = weak(o.y3); // 5 U would reach 7 U in the x2 role of the next pair
 #pragma unroll
             for (int l = 0; l < NL; l++) {
-                lds[l * E + e0] = y0.d[l];
-                lds[l * E + e1] = y1.d[l];
-                lds[l * E + e2] = y2.d[l];
+                lds[l * E + e0] = o.y0.d[l];
+                lds[l * E + e1] = o.y1.d[l];
+                lds[l * E + e2] = o.y2.d[l];
                 lds[l * E + e3] = y3.d[l];
             }
         }
@@ -448,7 +471,7 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
             uint32_t c, j;
             if (A.store_b_fast) { c = gq & (cols - 1); j = gq >> A.log_cols; } else { j = gq & (quarter - 1); c = gq >> (A.log_s - 2); }
             const uint32_t cb = c * S;
-            FrL x0, x1, x2, x3;
+            FrS x0, x1, x2, x3;
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 x0.d[l] = lds[l * E + cb + lds_pos(j)];
@@ -456,29 +479,20 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
                 x2.d[l] = lds[l * E + cb + lds_pos(j + 2 * m)];
                 x3.d[l] = lds[l * E + cb + lds_pos(j + 3 * m)];
             }
-            FrL y0, y1, y2, y3;
-            if (A.debug_skip & 1) {
-                y0 = x0; y1 = x1; y2 = x2; y3 = x3;
-            } else {
-                const FeT<Fr> w1 = load_tw(A.tw_sub, j << 1);
-                const auto t1 = mul(w1, x1), t3 = mul(w1, x3);
-                const auto a0 = add(x0, t1);
-                const auto a1 = sub(x0, t1);
-                const auto a2 = add(x2, t3);
-                const auto a3 = sub(x2, t3);
-                const FeT<Fr> w2a = load_tw(A.tw_sub, j);
-                const FeT<Fr> w2b = load_tw(A.tw_sub, j + m);
-                const auto u2 = mul(w2a, a2), u3 = mul(w2b, a3);
-                y0 = assume_bound<1, NTT_VMAX>(weak(add(a0, u2)));
-                y2 = assume_bound<1, NTT_VMAX>(weak(sub(a0, u2)));
-                y1 = assume_bound<1, NTT_VMAX>(weak(add(a1, u3)));
-                y3 = assume_bound<1, NTT_VMAX>(weak(sub(a1, u3)));
-            }
             const uint32_t b = b0 + c;
-            ntt_finish_store<FLAGS>(A, y0, j, b);
-            ntt_finish_store<FLAGS>(A, y1, j + m, b);
-            ntt_finish_store<FLAGS>(A, y2, j + 2 * m, b);
-            ntt_finish_store<FLAGS>(A, y3, j + 3 * m, b);
+            if (A.debug_skip & 1) {
+                ntt_finish_store<FLAGS>(A, x0, j, b);
+                ntt_finish_store<FLAGS>(A, x1, j + m, b);
+                ntt_finish_store<FLAGS>(A, x2, j + 2 * m, b);
+                ntt_finish_store<FLAGS>(A, x3, j + 3 * m, b);
+            } else {
+                // the outputs go straight into the twist / scaling product or into reduce_value(): no renormalisation at all
+                const Radix4Out o = radix4_lazy(x0, x1, x2, x3, load_tw(A.tw_sub, j << 1), load_tw(A.tw_sub, j), load_tw(A.tw_sub, j + m));
+                ntt_finish_store<FLAGS>(A, o.y0, j, b);
+                ntt_finish_store<FLAGS>(A, o.y1, j + m, b);
+                ntt_finish_store<FLAGS>(A, o.y2, j + 2 * m, b);
+                ntt_finish_store<FLAGS>(A, o.y3, j + 3 * m, b);
+            }
         }
     } else {
         const uint32_t half = S >> 1, nbf = cols * half; // s = log_s - 1
@@ -486,24 +500,21 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
             uint32_t c, j;
             if (A.store_b_fast) { c = bf & (cols - 1); j = bf >> A.log_cols; } else { j = bf & (half - 1); c = bf >> (A.log_s - 1); }
             const uint32_t cb = c * S;
-            FrL x, y;
+            FrS x, y;
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 x.d[l] = lds[l * E + cb + lds_pos(j)];
                 y.d[l] = lds[l * E + cb + lds_pos(j + half)];
             }
-            FrL xs, ys;
-            if (A.debug_skip & 1) {
-                xs = x; ys = y;
-            } else {
-                const FeT<Fr> w = load_tw(A.tw_sub, j);
-                const auto t = mul(w, y);
-                xs = assume_bound<1, NTT_VMAX>(weak(add(x, t)));
-                ys = assume_bound<1, NTT_VMAX>(weak(sub(x, t)));
-            }
             const uint32_t b = b0 + c;
-            ntt_finish_store<FLAGS>(A, xs, j, b);
-            ntt_finish_store<FLAGS>(A, ys, j + half, b);
+            if (A.debug_skip & 1) {
+                ntt_finish_store<FLAGS>(A, x, j, b);
+                ntt_finish_store<FLAGS>(A, y, j + half, b);
+            } else {
+                const auto t = exact_limbs(mul(load_tw(A.tw_sub, j), y));
+                ntt_finish_store<FLAGS>(A, assume_bound<5, NTT_VMAX>(add(x, t)), j, b);      // 5 U
+                ntt_finish_store<FLAGS>(A, assume_bound<6, NTT_VMAX>(sub(x, t)), j + half, b); // 6 U: still a legal factor
+            }
         }
     }
 }
