@@ -41,6 +41,16 @@ python tools/msm_ab.py > $OUT/msm_ab.txt 2>&1
 python tools/small_sizes.py > $OUT/small_sizes.txt 2>&1
 python tools/exchange_cost.py > $OUT/exchange_cost.txt 2>&1
 python tools/host_finish_cost.py > $OUT/host_finish_cost.txt 2>&1
+python tools/share_ab.py 8 4 2 > $OUT/share_ab.txt 2>&1
+python tools/skewed_stages.py > $OUT/skewed_stages.txt 2>&1
+python tools/boundary_ab.py > $OUT/boundary_ab.txt 2>&1
+BBGPU_HOST_MSM_SPLIT=1 python tools/boundary_ab.py >> $OUT/boundary_ab.txt 2>&1
+python tools/acc_ab.py > $OUT/acc_ab.txt 2>&1
+[ -f barretenberg_amd/_variants/libbbgpu_r2.so ] && BBGPU_LIB=$ROOT/barretenberg_amd/_variants/libbbgpu_r2.so python tools/acc_ab.py >> $OUT/acc_ab.txt 2>&1
+$ROOT/tools/ubench/ubench_pcie > $OUT/pcie.txt 2>&1
+export OMP_NUM_THREADS=16
+for w in 0 2; do BB_WARM_PROOFS=$w BBGPU_SHIM_PROFILE=$OUT/shim_profile_w$w.json oracle/_ref/plonk_gpu prove 65536 > /dev/null 2>> $OUT/shim_profile.log; done
+BB_WARM_PROOFS=1 oracle/_ref/plonk_cpu prove 65536 > /dev/null 2>> $OUT/shim_profile.log
 echo "== plain bench line"
 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 tail -c 400 $OUT/${TAG}_bench_line.json
