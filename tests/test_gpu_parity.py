@@ -557,7 +557,15 @@ def test_msm_around_the_table_mode_switch(gpu, oracle, golden):
     d_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
     for case in g["threshold"]:
         n = case["n"]
-        h = gpu.srs_generate(x, n)
+        if n == 3 << 18:
+            # the same through the HOST-pointer entry (bbgpu_msm_g1): from 2^19 points on it runs as two point ranges (3/8 + 5/8 of the
+            # points, the second range's scalars crossing the link under the first one's kernels) whose partial sums are added on the host
+            h, table = gpu.srs_generate(x, n, True)
+            _check(gpu.pippenger(aligned_copy(scalars[:n]), table, n), case)
+            for m in ((1 << 19) + 8, 1 << 19, (1 << 19) - 8):  # prefixes of the same table: two ranges, two ranges, one range
+                _check(gpu.pippenger(aligned_copy(scalars[:m]), table, m), [c for c in g["threshold"] if c["n"] == m][0])
+        else:
+            h = gpu.srs_generate(x, n)
         _check(gpu.msm_device(h, d_sc.data_ptr(), n), case)
         # a prefix of a LARGER table keeps that table's window size: the 2^19 - 8 prefix on 17-bit tables, too
         if n == (1 << 19) + 8:
