@@ -16,6 +16,7 @@
 #include "host_g1.hpp"
 #include "host_g2.hpp"
 #include "host_small.hpp"
+#include "host_copy_pool.hpp"
 #include "poly.h"
 
 namespace bbgpu {
@@ -179,6 +180,8 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
 // library's own: CPU memcpy (30-50 GB/s on the boxes' EPYC 9575F), DMA from / to pinned memory, the copy of chunk k+1 under the DMA of
 // chunk k.  Larger buffers keep the direct path: there a copy is 0.6 ms per 32 MiB against ~1 ms through one staging thread, and the
 // stall is small against the work (profiles/r03_pcie.txt).
+static host::CopyPool g_copy_pool; // CPU copies into / out of the pinned staging buffers (host_copy_pool.hpp)
+
 int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
 {
     read_host_env();
@@ -197,7 +200,7 @@ int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
         const size_t len = std::min(CH, bytes - off);
         const int k = (int)(g_ctx.h_stage_next++ & 1);
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k])); // the DMA that last read this buffer has finished (no-op before its first use)
-        memcpy(g_ctx.h_stage[k], (const char*)h_src + off, len);
+        g_copy_pool.copy(g_ctx.h_stage[k], (const char*)h_src + off, len);
         CHK(hipMemcpyAsync((char*)d_dst + off, g_ctx.h_stage[k], len, hipMemcpyHostToDevice, st));
         CHK(hipEventRecord(g_ctx.h_stage_free[k], st));
     }
@@ -239,12 +242,13 @@ int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_
             if (int rc = enqueue(c + 1)) return rc;
         const int k = kbuf[c & 1];
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k]));
-        memcpy((char*)h_dst + c * CH, g_ctx.h_stage[k], std::min(CH, bytes - c * CH));
+        g_copy_pool.copy((char*)h_dst + c * CH, g_ctx.h_stage[k], std::min(CH, bytes - c * CH));
     }
     return BBGPU_OK;
 }
 void host_stage_release()
 {
+    g_copy_pool.shutdown();
     for (int k = 0; k < 2; k++) {
         if (g_ctx.h_stage[k]) (void)hipHostFree(g_ctx.h_stage[k]);
         if (g_ctx.h_stage_free[k]) (void)hipEventDestroy(g_ctx.h_stage_free[k]);
