@@ -116,11 +116,14 @@ int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_tab
 
 /* drop-in for scalar_multiplication::pippenger(scalars, points, n, bucket_width) (:457-476); scalars not modified.
  * out = {x, y, z} normalised, or infinity flag set (n == 0, all-zero scalars).
- * Representation note: a sum that IS the point at infinity comes back as the clean encoding (all limbs zero, bit 63 of y limb 3 set).
- * The reference's Prover pushes such a result through g1::jacobian_to_affine (prover.cpp:73-132), which leaves whatever the CPU
- * algorithm's accumulators held in x, y -- an unspecified off-curve pair that only the reference's own code path reproduces; a proof
- * that commits to an all-zero polynomial (zero selector, all-zero witness) therefore hashes differently under the two builds.  Every
- * other result is the unique affine point and is bit-identical. */
+ * A sum that IS the point at infinity comes back as the clean encoding (all limbs zero, bit 63 of y limb 3 set).  What the reference emits
+ * for it is pinned by tests/golden/infinity_commitments.json: g1::normalize() re-sets the flag (group.hpp:450-468) and every other bit of the
+ * pair is whatever the CPU algorithm's accumulators held in that run -- it changes with the OpenMP thread count, and through the Fiat-Shamir
+ * hash so does the rest of such a proof.  The flag is all there is to reproduce; the reference's Verifier accepts proofs carrying the clean
+ * encoding (tests/test_gpu_plonk.py::test_commitments_at_infinity).  Every other result is the unique affine point and is bit-identical.
+ * From 2^19 points on the call runs as two point ranges through the two-slot pipeline (the second range's scalars cross the link under the
+ * first one's kernels; BBGPU_HOST_MSM_SPLIT).  Host buffers of up to 8 MiB (BBGPU_STAGE_MAX_BYTES) are copied through the library's own
+ * pinned staging buffers rather than pinned in place by the runtime. */
 int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12]);
 /* the same sum over a PLAIN table: `points` = n affine points, 64 bytes apart -- the argument convention of the reference's
  * pippenger_low_memory(scalars, points, num_points) (scalar_multiplication.cpp:142-262, which applies beta itself; its test allocates
