@@ -46,6 +46,39 @@ while time.time() < t_end:
         print("MISMATCH n=%d kind=%d" % (n, kind), flush=True)
 print("oracle comparisons: %d cases, %d mismatches" % (cases, bad), flush=True)
 
+# shares (round 3): N bucket-range shares and N row-range shares of random sizes / scalar mixtures must add up to the one-call result
+t2 = time.time() + budget / 4
+share_cases = share_bad = 0
+while time.time() < t2:
+    n = int(rng.integers(1024, 20000))
+    if rng.integers(0, 2) == 0:
+        n &= ~7
+    sc = pool[rng.permutation(N)[:n]].copy()
+    kind = int(rng.integers(0, 4))
+    if kind == 1:
+        pick = rng.integers(0, 4, n); sc[pick == 0] = zero; sc[pick == 1] = one; sc[pick == 2] = minus_one
+    elif kind == 2:
+        sc[:] = pool[int(rng.integers(0, N))]
+    tab = aligned_copy(table[:2 * n])
+    h = G.srs_register(tab)
+    d = torch.from_numpy(aligned_copy(sc).view(np.int64)).cuda()
+    full = G.msm_device(h, d.data_ptr(), n)
+    W = G.srs_num_windows(h, n)
+    Nn = int(rng.integers(1, 9))
+    tickets = [G.msm_device_buckets_async(h, d.data_ptr(), n, r, Nn) for r in range(min(Nn, 4))]
+    parts = [G.msm_wait(t) for t in tickets] + [G.msm_wait(G.msm_device_buckets_async(h, d.data_ptr(), n, r, Nn)) for r in range(4, Nn)]
+    okb = np.array_equal(G.g1_sum(np.stack(parts)), full)
+    cuts = [W * n * r // Nn for r in range(Nn + 1)]
+    parts = [G.msm_wait(G.msm_device_rows_async(h, d.data_ptr(), n, a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
+    okr = np.array_equal(G.g1_sum(np.stack(parts)), full)
+    share_cases += 1
+    if not (okb and okr):
+        share_bad += 1
+        print("SHARE MISMATCH n=%d kind=%d N=%d buckets_ok=%s rows_ok=%s" % (n, kind, Nn, okb, okr), flush=True)
+    G.srs_release(h)
+print("share splits: %d cases (bucket and row shares, 1..8 ranks), %d mismatches" % (share_cases, share_bad), flush=True)
+bad += share_bad
+
 # pipelined: 4 different scalar vectors, two and three in flight, against their one-at-a-time results, at 2^15 and 2^20
 for lg in (15, 20):
     n = 1 << lg
