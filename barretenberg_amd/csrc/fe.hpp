@@ -429,7 +429,8 @@ template <class F, int L1, int V1> BB_HD Fe<F, 1, mul_v(V1, V1)> sqr(const Fe<F,
 }
 
 // value < V*p  ->  value' == value (mod p), value' < 3p, tight limbs.  ~60 instructions.
-template <class F, int L, int V> BB_HD Fe<F, 1, 3> reduce_value(const Fe<F, L, V>& a)
+// (reduce_value_raw: the same without the final carry round, limbs up to 3 U -- for a consumer that carries anyway, to_canonical)
+template <class F, int L, int V> BB_HD Fe<F, 3, 3> reduce_value_raw(const Fe<F, L, V>& a)
 {
     Fe<F, 1, V> t = carry_full(a);
     // q <= floor(value / p), q >= that - 2
@@ -452,7 +453,11 @@ template <class F, int L, int V> BB_HD Fe<F, 1, 3> reduce_value(const Fe<F, L, V
         if (i > 0) v -= 1u;
         r.d[i] = v;
     }
-    return weak(r);
+    return r;
+}
+template <class F, int L, int V> BB_HD Fe<F, 1, 3> reduce_value(const Fe<F, L, V>& a)
+{
+    return weak(reduce_value_raw(a));
 }
 
 // ---- memory format: 8 x u32 little-endian words (== the reference's 4 x u64 field_t) ---------------------------
@@ -517,11 +522,19 @@ template <class F, int L, int V> BB_HD void to_canonical(const Fe<F, L, V>& a, u
         if constexpr (V > 2) cond_sub_256(w, F::P2_64);
         if constexpr (V > 1) cond_sub_256(w, F::P64);
     } else {
-        Fe<F, 1, 3> r = reduce_value(a);
-        pack_exact(carry_full(r), w);
+        pack_exact(carry_full(reduce_value_raw(a)), w);
         cond_sub_256(w, F::P2_64);
         cond_sub_256(w, F::P64);
     }
+}
+
+// the same for a value whose limbs are already exact (a product): no carry chain
+template <class F, int V> BB_HD void to_canonical(const FeE<F, V>& a, uint32_t (&w)[8])
+{
+    static_assert(V <= 4, "value may not fit 256 bits");
+    pack_exact(a, w);
+    if constexpr (V > 2) cond_sub_256(w, F::P2_64);
+    if constexpr (V > 1) cond_sub_256(w, F::P64);
 }
 
 // k * p in exact 29-bit limbs

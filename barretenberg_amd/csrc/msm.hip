@@ -320,7 +320,7 @@ template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_ke
     unsigned long long* __restrict__ signs = signs_all + (size_t)blockIdx.y * num_windows * s64;
     uint32_t w[8], k[9];
     ld8(scalars + (size_t)i * 8, w);
-    to_canonical(mul(unpack<Fr>(w), fe_from<Fr>(Fr::M256_TO_PLAIN)), w); // x*2^256 * 2^5 / 2^261 = x, canonical
+    to_canonical(exact_limbs(mul(unpack<Fr>(w), fe_from<Fr>(Fr::M256_TO_PLAIN))), w); // x*2^256 * 2^5 / 2^261 = x, canonical (a product: no carry chain before packing)
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = w[j];
     k[8] = 0;

@@ -315,13 +315,11 @@ template <int FLAGS, int L> __device__ __forceinline__ void ntt_finish_store(con
         uint32_t tw8[8];
         load8(A.twist_full + 8 * gidx, tw8);
         const FeT<Fr> tw = assume_bound<1, 1>(unpack<Fr>(tw8));
-        auto r = mul(x, tw);
-        pack(r, w);
+        pack_exact(mul(x, tw), w); // a product: limbs exact, value < 2p < 2^256 -- no carry chain
     } else if constexpr (FLAGS & 2) {
         const uint32_t ex = b * k; // < n
         auto tw = mul(load_tw(A.twist_lo, ex & ((1u << A.lo_bits) - 1)), load_tw(A.twist_hi, ex >> A.lo_bits));
-        auto r = mul(x, tw); // 48 * 2 / 169 + 2 = 2  -> fits 256 bits
-        pack(r, w);
+        pack_exact(mul(x, tw), w); // 48 * 2 / 169 + 2 = 2  -> fits 256 bits; a product's limbs are exact
     } else {
         Fe<Fr, 1, 3> r;
         if constexpr (FLAGS & 128) {
@@ -336,10 +334,9 @@ template <int FLAGS, int L> __device__ __forceinline__ void ntt_finish_store(con
             r = mul(x, g);
         } else if constexpr (FLAGS & 8) {
             r = mul(x, fe_from<Fr>(A.post_const));
-        } else {
-            r = reduce_value(x);
         }
-        to_canonical(r, w);
+        if constexpr ((FLAGS & (128 | 4 | 8)) != 0) to_canonical(exact_limbs(r), w); // r is a product in every one of these branches
+        else to_canonical(x, w); // plain transform: value reduction, ONE carry chain, two conditional subtractions
     }
     store8(A.out + (size_t)blockIdx.y * A.out_bstride + 8 * gidx, w);
 }
