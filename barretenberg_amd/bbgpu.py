@@ -19,6 +19,10 @@ except Exception:  # pragma: no cover - torch is optional for the library itself
     torch = None
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of two streams that share a queue run one
+# after the other.  The library's MSM slots want their own queues (libbbgpu sets the same default when it makes the process's first HIP call);
+# effective only if HIP has not been initialised yet -- import this module before torch touches the GPU, or export the variable.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 u64p = C.POINTER(C.c_uint64)
 
 NTT_KINDS = {
@@ -275,7 +279,7 @@ class BbGpu:
         return out
 
     def msm_device_async(self, handle, d_scalars_ptr, n, offset=0, window_begin=0, window_end=None, stream=None):
-        """enqueue; returns a ticket for msm_wait().  At most four MSMs in flight."""
+        """enqueue; returns a ticket for msm_wait().  At most eight MSMs in flight."""
         if window_end is None:
             window_end = self.srs_num_windows(handle, n)
         return self._chk(self.lib.bbgpu_msm_g1_device_async(handle, offset, C.c_void_p(d_scalars_ptr), n, window_begin, window_end,

@@ -66,7 +66,7 @@ struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<SrsEntry> srs;
-    static constexpr int NSLOT = 4; // asynchronous MSMs in flight (each with its own workspace and stream)
+    static constexpr int NSLOT = 8; // asynchronous MSMs in flight (each with its own workspace and stream; workspaces are allocated on first use)
     MsmSlot slot[NSLOT];
     int next_slot = 0;
     uint64_t* d_stage = nullptr; // scalars / coefficients staging
@@ -127,6 +127,12 @@ void read_host_env()
 int ensure_init()
 {
     if (g_ctx.ready) return BBGPU_OK;
+    // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of two streams that
+    // share a queue run one after the other.  With the caller's streams beside them the four MSM slot streams landed on TWO queues: "three in
+    // flight" was slower than two for that reason alone (rocprofv3 timeline; 2^16-point MSMs three in flight 0.168 -> 0.127 ms per
+    // MSM with 8 queues, a 1/8 share four in flight 0.232 -> 0.205).  Only effective when this is the process's first HIP call; a host
+    // program that initialises HIP earlier sets the variable itself (bench.py and the Python binding do).
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
         set_error("no HIP device available: libbbgpu has no CPU fallback");
@@ -365,6 +371,17 @@ bool windows_resident(const SrsEntry& e, int wb, int we)
     if (!e.d_tab || (wb >= e.tab_wb && we <= e.tab_we)) return true;
     set_error("windows [%d, %d) requested, this table keeps [%d, %d) of %d (bbgpu_set_table_share)", wb, we, e.tab_wb, e.tab_we, e.tab_W);
     return false;
+}
+// A free slot for an asynchronous MSM: slots 0 / 1 alternate for consecutive calls (two large MSMs in flight is the measured optimum for the
+// full-size pipeline), the others take whatever else is in flight (shares of a split MSM, small MSMs: up to eight).  -1: all busy.
+int pick_slot()
+{
+    int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1 };
+    for (int k = 2; k < Context::NSLOT; k++) order[k] = k;
+    for (int k = 0; k < Context::NSLOT; k++)
+        if (!g_ctx.slot[order[k]].pending) return order[k];
+    set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
+    return -1;
 }
 int issue_on_entry(MsmSlot& S, const SrsEntry& e, size_t off, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st)
 {
@@ -1217,14 +1234,8 @@ int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_s
     // slots 0 and 1 alternate (the two-deep pipeline of consecutive large MSMs: measured 1.50 ms/step against 1.72 when four
     // streams rotate -- more streams than hardware queues delay the next MSM's sort behind the previous one's tail);
     // slots 2 and 3 only take the overflow when both are busy (a prover round's three side-by-side commitments)
-    int t = -1;
-    const int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1, 2, 3 };
-    for (int k = 0; k < Context::NSLOT; k++)
-        if (!g_ctx.slot[order[k]].pending) { t = order[k]; break; }
-    if (t < 0) {
-        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
-        return BBGPU_ERR_STATE;
-    }
+    const int t = pick_slot();
+    if (t < 0) return BBGPU_ERR_STATE;
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
@@ -1261,14 +1272,8 @@ int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t
         set_error("row-range shares need the pre-shifted window tables (one shared bucket set): this table has none");
         return BBGPU_ERR_STATE;
     }
-    int t = -1;
-    const int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1, 2, 3 };
-    for (int k = 0; k < Context::NSLOT; k++)
-        if (!g_ctx.slot[order[k]].pending) { t = order[k]; break; }
-    if (t < 0) {
-        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
-        return BBGPU_ERR_STATE;
-    }
+    const int t = pick_slot();
+    if (t < 0) return BBGPU_ERR_STATE;
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
@@ -1298,14 +1303,8 @@ int bbgpu_msm_g1_device_buckets_async(int srs_handle, size_t offset, const uint6
         set_error("bucket-range shares need the pre-shifted window tables (one shared bucket set): this table has none");
         return BBGPU_ERR_STATE;
     }
-    int t = -1;
-    const int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1, 2, 3 };
-    for (int k = 0; k < Context::NSLOT; k++)
-        if (!g_ctx.slot[order[k]].pending) { t = order[k]; break; }
-    if (t < 0) {
-        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
-        return BBGPU_ERR_STATE;
-    }
+    const int t = pick_slot();
+    if (t < 0) return BBGPU_ERR_STATE;
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
@@ -1339,14 +1338,8 @@ int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_
         set_error("batched MSM needs an SRS registered with window tables (bbgpu_set_precompute, 1024 <= n <= 2^20)");
         return BBGPU_ERR_ARG;
     }
-    int t = -1;
-    const int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1, 2, 3 };
-    for (int k = 0; k < Context::NSLOT; k++)
-        if (!g_ctx.slot[order[k]].pending) { t = order[k]; break; }
-    if (t < 0) {
-        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
-        return BBGPU_ERR_STATE;
-    }
+    const int t = pick_slot();
+    if (t < 0) return BBGPU_ERR_STATE;
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;

@@ -83,6 +83,7 @@ if __name__ == "__main__":
     if _rc is not None:
         sys.exit(_rc)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP is initialised: the MSM slot streams get hardware queues of their own
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -444,9 +445,9 @@ def main():
         return part
 
     exchange = PartialSumExchange(G, world, xdev) if world > 1 else None
-    # shares in flight: two at N <= 2 (the full MSM measured worse with more: one more front / tail competing with the accumulation), four from
-    # N = 4 on, where a share is a chain of short launches (tools/share_ab.py, a middle 1/8 row share: 0.362 / 0.248 / 0.268 / 0.226 ms per
-    # step with 1 / 2 / 3 / 4 in flight; 1/4: 0.571 / 0.364 / 0.431 / 0.358)
+    # shares in flight: two at N <= 2 (more changes nothing there: the step is the accumulation), four from N = 4 on, where a share is a chain of
+    # short launches (tools/share_ab.py with GPU_MAX_HW_QUEUES=8, a middle 1/8 row share: 0.362 / 0.254 / 0.217 / 0.213 / 0.232 / 0.219 ms per step
+    # with 1 / 2 / 3 / 4 / 6 / 8 in flight; 1/4: 0.589 / 0.372 / 0.350 / 0.348 / 0.351 / 0.359)
     depth = 4 if world >= 4 else 2
 
     def run_steps(k):

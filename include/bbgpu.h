@@ -157,7 +157,7 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs);
 int bbgpu_msm_num_windows(size_t n);
 int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                         int window_end, uint64_t out[12], void* hip_stream);
-/* Asynchronous form: enqueue (returns a ticket >= 0, or a negative error) and collect later.  Up to four MSMs may be in
+/* Asynchronous form: enqueue (returns a ticket >= 0, or a negative error) and collect later.  Up to eight MSMs may be in
  * flight; the bucket-reduction tail and host finish of one then overlap the sort/accumulate of the next, and
  * small latency-bound MSMs (a prover round's three commitments) run side by side.  With hip_stream == NULL each ticket runs
  * on its own internal stream. */
@@ -183,7 +183,7 @@ int bbgpu_msm_g1_wait(int ticket, uint64_t out[12]);
  * prover.cpp:65-122,650-658): `jobs` (1..4) resident scalar vectors of n scalars each against points [offset, offset + n) of a
  * table registered WITH window tables, issued as ONE pass through the pipeline -- one bucket set per job in the shared sort /
  * accumulate / merge / reduction kernels -- so the batch pays one chain of launches and dependent additions, not `jobs`.
- * bbgpu_msm_g1_batch_wait writes jobs x 12 limbs (normalised).  Uses one of the four tickets. */
+ * bbgpu_msm_g1_batch_wait writes jobs x 12 limbs (normalised).  Uses one of the eight tickets. */
 int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_t* const* d_scalars, int jobs, size_t n, void* hip_stream);
 int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out);
 /* out = sum of `count` normalised/Jacobian points (infinity flags honoured), normalised.  Host arithmetic. */

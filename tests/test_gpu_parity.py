@@ -431,14 +431,14 @@ def test_msm_async_pipeline(gpu, oracle, msm_small):
         if len(inflight) == 2:
             m, t = inflight.pop(0)
             got.append((m, gpu.msm_wait(t)))
-    with pytest.raises(BbGpuError):  # one is still in flight and there are four slots: the fourth extra enqueue must be refused
-        for _ in range(4):
+    with pytest.raises(BbGpuError):  # one is still in flight and there are eight slots: the eighth extra enqueue must be refused
+        for _ in range(8):
             gpu.msm_device_async(h, d[16].data_ptr(), 16)
     while inflight:
         m, t = inflight.pop(0)
         got.append((m, gpu.msm_wait(t)))
     # drain whatever the failed double-issue left behind
-    for t in (0, 1, 2, 3):
+    for t in range(8):
         try:
             gpu.msm_wait(t)
         except BbGpuError:

@@ -26,6 +26,6 @@ def timed(issue, depth):
     return float(np.median(ts)) * 1e3
 for N in [int(a) for a in (sys.argv[1:] or ["8"])]:
     rows = W * n // N
-    r = "rows    N=%d:" % N + "".join("  %d in flight %.3f" % (dp, timed(lambda: G.msm_device_rows_async(srs, d.data_ptr(), n, rows * (N // 2), rows * (N // 2 + 1)), dp)) for dp in (1, 2, 3, 4))
-    b = "buckets N=%d:" % N + "".join("  %d in flight %.3f" % (dp, timed(lambda: G.msm_device_buckets_async(srs, d.data_ptr(), n, N // 2, N), dp)) for dp in (1, 2, 3, 4))
+    r = "rows    N=%d:" % N + "".join("  %d in flight %.3f" % (dp, timed(lambda: G.msm_device_rows_async(srs, d.data_ptr(), n, rows * (N // 2), rows * (N // 2 + 1)), dp)) for dp in (1, 2, 3, 4, 6, 8))
+    b = "buckets N=%d:" % N + "".join("  %d in flight %.3f" % (dp, timed(lambda: G.msm_device_buckets_async(srs, d.data_ptr(), n, N // 2, N), dp)) for dp in (1, 2, 3, 4, 6, 8))
     print(r, flush=True); print(b, flush=True)
