@@ -6,6 +6,7 @@
 // 512 KiB or more.  Started on first use, joined by shutdown() / at process exit; no GPU calls on these threads.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,9 @@ public:
             std::memcpy(dst, src, bytes);
             return;
         }
+#ifdef BBGPU_COPY_POOL_TEST_DELAY // tests/cpp/test_host_sanitize.cpp: give freshly started helpers time to run before the job is posted
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+#endif
         const size_t parts = (size_t)helpers + 1;
         const size_t part = ((bytes / parts) + 4095) & ~(size_t)4095; // page-sized pieces
         {
@@ -74,12 +78,14 @@ private:
         if (const char* e = std::getenv("BBGPU_STAGE_THREADS")) n = std::max(0, std::min(15, std::atoi(e)));
         std::lock_guard<std::mutex> lk(mu_);
         started_ = true;
-        for (int i = 0; i < n; i++) threads_.emplace_back([this, i] { worker((size_t)i + 1); });
+        // a helper starts from the CURRENT generation: after a shutdown() / restart the counter is not zero, and a helper that compared it with
+        // zero would "see" a job at once and copy between the pointers of the last job before the shutdown (a freed staging buffer)
+        const unsigned long long g0 = generation_;
+        for (int i = 0; i < n; i++) threads_.emplace_back([this, i, g0] { worker((size_t)i + 1, g0); });
         return n;
     }
-    void worker(size_t idx)
+    void worker(size_t idx, unsigned long long seen)
     {
-        unsigned long long seen = 0;
         for (;;) {
             char* dst;
             const char* src;

@@ -137,7 +137,7 @@ def test_host_code_under_sanitizers(oracle):
     exe = os.path.join(tempfile.gettempdir(), "bbgpu_test_host_sanitize")
     ob = os.path.join(ROOT, "oracle", "_build")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
-           os.path.join(ROOT, "tests", "cpp", "test_host_sanitize.cpp"), "-L" + ob, "-loracle", "-Wl,-rpath," + ob]
+           os.path.join(ROOT, "tests", "cpp", "test_host_sanitize.cpp"), "-L" + ob, "-loracle", "-Wl,-rpath," + ob, "-pthread"]
     b = subprocess.run(cmd, capture_output=True, text=True)
     if b.returncode != 0 and ("asan" in b.stderr or "ubsan" in b.stderr or "sanitize" in b.stderr):
         pytest.skip("no sanitizer runtime in this image: " + b.stderr[-200:])
