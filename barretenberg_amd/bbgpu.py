@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of two streams that share a queue run one
 # after the other.  The library's MSM slots want their own queues (libbbgpu sets the same default when it makes the process's first HIP call);
 # effective only if HIP has not been initialised yet -- import this module before torch touches the GPU, or export the variable.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 u64p = C.POINTER(C.c_uint64)
 
 NTT_KINDS = {

@@ -130,9 +130,9 @@ int ensure_init()
     // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of two streams that
     // share a queue run one after the other.  With the caller's streams beside them the four MSM slot streams landed on TWO queues: "three in
     // flight" was slower than two for that reason alone (rocprofv3 timeline; 2^16-point MSMs three in flight 0.168 -> 0.127 ms per
-    // MSM with 8 queues, a 1/8 share four in flight 0.232 -> 0.205).  Only effective when this is the process's first HIP call; a host
+    // MSM with 8 queues, a 1/8 share four in flight 0.232 -> 0.205).  16: the eight slot streams, the library's own and the caller's.  Only effective when this is the process's first HIP call; a host
     // program that initialises HIP earlier sets the variable itself (bench.py and the Python binding do).
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
         set_error("no HIP device available: libbbgpu has no CPU fallback");
@@ -140,6 +140,10 @@ int ensure_init()
     }
     CHK(hipSetDevice(g_ctx.device));
     CHK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    // the slot streams are made HERE, one after the other: the runtime deals streams to hardware queues in creation order, and a slot
+    // stream created later (first use of a third slot, in a process that has made other streams meanwhile) can land on the queue of another slot
+    for (auto& sl : g_ctx.slot)
+        if (!sl.stream) CHK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
     CHK(hipEventCreateWithFlags(&g_ctx.shared_done, hipEventDisableTiming));
     g_ctx.shared_used = false;
     if (const char* e = getenv("BBGPU_SRS_CACHE_BYTES")) g_ctx.srs_cache_cap = (size_t)strtoull(e, nullptr, 0);

@@ -83,7 +83,7 @@ if __name__ == "__main__":
     if _rc is not None:
         sys.exit(_rc)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP is initialised: the MSM slot streams get hardware queues of their own
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before HIP is initialised: the MSM slot streams get hardware queues of their own
 import numpy as np
 import torch
 import torch.distributed as dist
