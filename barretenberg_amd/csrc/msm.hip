@@ -359,6 +359,8 @@ template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_ke
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 1024;
 constexpr uint32_t SORT_MAX_LB = 7;
+constexpr uint32_t SORTB_MAX_PARTS = 8;       // pieces a HEAVY bin is cut into by pass B of a large MSM
+constexpr uint32_t SORTB_SPLIT_MIN = 1u << 16; // ... a bin with more entries than this
 
 // LDS counter increments for keys that may be heavily duplicated inside a wave.  With uniform digits the 64 lanes of a wave hit ~60 different
 // counters and the plain LDS atomic is the right tool; with skewed scalars (every scalar equal, 0 / 1 / -1 witnesses: what real circuits hold) all
@@ -715,9 +717,44 @@ __global__ void __launch_bounds__(SORT_THREADS) sortB_kernel(const uint32_t* __r
 // per wave store, and the L2 takes ~128 requests per clock chip-wide -- 15.7M entries = 58 us of request issue alone (measured 74 us).
 // Here a tile of 8 entries per lane is ranked by sub-bucket in LDS (LDS atomics), laid out sub-bucket by sub-bucket in a 32 KiB
 // buffer, and written out with consecutive lanes on consecutive addresses: runs of ~64 entries = two full 128-byte lines per sub-bucket and tile.
+// Large MSMs (round 3): a bin is cut into `parts` contiguous pieces, one workgroup each (blockIdx.z) -- under skewed digit distributions a
+// single bin holds up to n entries (every scalar equal: 15 bins of 2^20), and one workgroup walking 10^6 entries was ~1 ms of a 1.25 ms
+// sort.  The pieces' sub-bucket counts come from sortB_count_kernel (histB[group][bin][part][128]); a piece places its entries behind
+// those of the earlier pieces of its bin, so the result is the same stable order.  parts == 1 (small MSMs): the kernel counts its bin itself.
+template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_count_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binstart,
+                                                                                       const uint32_t* __restrict__ bases, uint32_t* __restrict__ histB, uint32_t bins, uint32_t parts)
+{
+    FRONT_PRIO();
+    constexpr int UB = 8;
+    constexpr uint32_t TILE = THREADS * UB;
+    __shared__ uint32_t cnt[128];
+    const uint32_t bin = blockIdx.x, wl = blockIdx.y, part = blockIdx.z, t = threadIdx.x;
+    const uint32_t bstart = bases[wl] + binstart[(size_t)wl * bins + bin];
+    const uint32_t bend = (bin + 1 < bins) ? bases[wl] + binstart[(size_t)wl * bins + bin + 1] : bases[wl + 1];
+    const uint32_t len = bend - bstart;
+    if (len <= SORTB_SPLIT_MIN) return; // an ordinary bin: its one workgroup of the scatter kernel counts it itself
+    const uint32_t start = bstart + (uint32_t)(((uint64_t)len * part) / parts), end = bstart + (uint32_t)(((uint64_t)len * (part + 1)) / parts);
+    if (t < 128) cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t e0 = start + t; e0 < end; e0 += TILE) {
+        uint32_t v[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const uint32_t e = e0 + k * THREADS;
+            v[k] = e < end ? tmp[e] : 0u;
+        }
+        const bool heavy = wave_keys_heavy(e0 < end, (v[0] >> 24) & 0x7f);
+#pragma unroll
+        for (int k = 0; k < UB; k++)
+            if (e0 + k * THREADS < end) (void)lds_inc_dedup(cnt, (v[k] >> 24) & 0x7f, heavy);
+    }
+    __syncthreads();
+    if (t < 128) histB[(((size_t)wl * bins + bin) * parts + part) * 128 + t] = cnt[t];
+}
 template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_staged_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binstart,
                                                                                         const uint32_t* __restrict__ bases, uint32_t* __restrict__ sorted,
-                                                                                        uint32_t* __restrict__ gstart, uint32_t bins, uint32_t lb, uint32_t nb)
+                                                                                        uint32_t* __restrict__ gstart, uint32_t bins, uint32_t lb, uint32_t nb,
+                                                                                        const uint32_t* __restrict__ histB, uint32_t parts_launched)
 {
     FRONT_PRIO();
     constexpr int UB = 8;
@@ -726,14 +763,34 @@ template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_staged_k
     __shared__ uint32_t cur[128];   // next global position per sub-bucket
     __shared__ uint32_t toff[128];  // first slot of the sub-bucket in the tile buffer
     __shared__ uint32_t dlt[128];   // global position - slot
+    __shared__ uint32_t bef[128];   // entries of the sub-bucket in the earlier pieces of this bin
     __shared__ uint32_t buf[TILE];
-    const uint32_t bin = blockIdx.x, wl = blockIdx.y, t = threadIdx.x;
+    const uint32_t bin = blockIdx.x, wl = blockIdx.y, part = blockIdx.z, t = threadIdx.x;
     const uint32_t nlo = 1u << lb;
-    const uint32_t start = bases[wl] + binstart[(size_t)wl * bins + bin];
-    const uint32_t end = (bin + 1 < bins) ? bases[wl] + binstart[(size_t)wl * bins + bin + 1] : bases[wl + 1];
-    if (t < 128) cnt[t] = 0;
+    const uint32_t bstart = bases[wl] + binstart[(size_t)wl * bins + bin];
+    const uint32_t bend = (bin + 1 < bins) ? bases[wl] + binstart[(size_t)wl * bins + bin + 1] : bases[wl + 1];
+    const uint32_t len = bend - bstart;
+    // only HEAVY bins (more than SORTB_SPLIT_MIN entries: skewed digits; a bin of uniform 2^20-point digits holds ~30 k) are cut into pieces;
+    // an ordinary bin is one workgroup's as before and the other pieces' workgroups leave at once
+    const uint32_t parts = (parts_launched > 1 && len > SORTB_SPLIT_MIN) ? parts_launched : 1u;
+    if (part >= parts) return;
+    // this workgroup's piece of the bin (the whole bin when parts == 1)
+    const uint32_t start = bstart + (uint32_t)(((uint64_t)len * part) / parts), end = bstart + (uint32_t)(((uint64_t)len * (part + 1)) / parts);
+    if (t < 128) {
+        uint32_t total = 0, before = 0;
+        if (parts > 1) {
+            const uint32_t* h = histB + (((size_t)wl * bins + bin) * parts) * 128 + t;
+            for (uint32_t p = 0; p < parts; p++) {
+                const uint32_t c = h[(size_t)p * 128];
+                total += c;
+                if (p < part) before += c;
+            }
+        }
+        cnt[t] = total;
+        bef[t] = before;
+    }
     __syncthreads();
-    for (uint32_t e0 = start + t; e0 < end; e0 += TILE) {
+    for (uint32_t e0 = start + t; parts == 1 && e0 < end; e0 += TILE) {
         uint32_t v[UB];
 #pragma unroll
         for (int k = 0; k < UB; k++) {
@@ -754,11 +811,14 @@ template <int THREADS> __global__ void __launch_bounds__(THREADS) sortB_staged_k
             const uint32_t o = __shfl_up(incl, off);
             if ((int)t >= off) incl += o;
         }
-        cur[2 * t] = start + incl - sum;
-        cur[2 * t + 1] = start + incl - sum + a;
+        cur[2 * t] = bstart + incl - sum;
+        cur[2 * t + 1] = bstart + incl - sum + a;
     }
     __syncthreads();
-    if (t < nlo) gstart[(size_t)wl * nb + (size_t)bin * nlo + t] = cur[t];
+    if (t < nlo && part == 0) gstart[(size_t)wl * nb + (size_t)bin * nlo + t] = cur[t];
+    __syncthreads();
+    if (t < 128) cur[t] += bef[t]; // this piece writes behind the earlier pieces of its bin
+    __syncthreads();
     for (uint32_t base = start; base < end; base += TILE) { // workgroup-uniform trip count
         if (t < 128) cnt[t] = 0;
         __syncthreads();
@@ -857,13 +917,20 @@ __device__ __forceinline__ void load_raw(Xyzz& p, const uint32_t* src)
 #define ACC_VGPR_CAP
 #endif
 constexpr int RAW_WORDS = 4 * NL; // 36 words per partial: lazy limbs, no canonicalisation on the hot path
+// The heavy-bucket queue of the merge: heavy[0] = number of queued buckets, heavy[1 .. HEAVY_WGS] = per-bucket arrival counters of the
+// workgroups that share a bucket (K4h), heavy[HEAVY_IDS ..] = bucket ids; HEAVY_WGS raw partial sums follow the id list (MsmCarve).
+constexpr uint32_t HEAVY_WGS = 256;           // workgroups of K4h
+constexpr uint32_t HEAVY_IDS = 1 + HEAVY_WGS; // first bucket id
 
 __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ gstart, uint32_t* __restrict__ partials,
                                                                    uint32_t total_buckets, uint32_t ch, uint32_t prio, uint32_t* __restrict__ heavy_counter)
 {
     // small MSMs are a chain of dependent launches: the merge's heavy-bucket counter is zeroed here instead of by a fill launch of its own
-    if (heavy_counter && blockIdx.x == 0 && threadIdx.x == 0) *heavy_counter = 0;
+    if (heavy_counter && blockIdx.x == 0) { // ... and the arrival counters behind it (HEAVY_IDS words; MSM_THREADS == HEAVY_WGS lanes + one)
+        heavy_counter[threadIdx.x] = 0;
+        if (threadIdx.x == 0) heavy_counter[MSM_THREADS] = 0;
+    }
     // wave priority above the memory-bound sort kernels of the NEXT MSM that share the CUs in the two-deep pipeline (they have
     // a whole accumulation of slack), below the latency-bound tail kernels of the previous one (s_setprio 3)
     if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -1038,8 +1105,8 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
     set_infinity(acc);
     if (e > s) {
         const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
-        if (t1 - t0 >= MERGE_LIGHT) { // heavy[0] = count, heavy[1..] = bucket ids
-            if (j == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
+        if (t1 - t0 >= MERGE_LIGHT) { // heavy[0] = count, heavy[HEAVY_IDS ..] = bucket ids
+            if (j == 0) heavy[HEAVY_IDS + atomicAdd(&heavy[0], 1u)] = b;
             return;
         }
         for (uint32_t k = t0 + j; k <= t1; k += G) {
@@ -1063,32 +1130,72 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
         st32(buckets + (size_t)b * 32, o);
     }
 }
-// K4h: one workgroup per queued bucket: strided in-lane sums, then the workgroup tree
+// K4h: the queued (heavy) buckets.  Many of them: one workgroup per bucket (strided in-lane sums, then the workgroup tree).  FEW of them
+// -- skewed digits: every scalar equal puts 2^20 entries, ~13 k partials, into each of 15 buckets -- : the gridDim.x workgroups are dealt
+// K = gridDim.x / count to a bucket, each sums a slice of its partials into a raw partial of its own (hpart), and the LAST of a bucket's
+// workgroups to arrive (agent-scope fences around an arrival counter) adds the K slices up (round 3: 0.45 -> ~0.1 ms for that case).
 __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
-                                                                    uint32_t* __restrict__ buckets, const uint32_t* __restrict__ heavy, uint32_t ch)
+                                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t ch, uint32_t* __restrict__ hpart)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[FOLD_LDS_WORDS];
+    __shared__ uint32_t last_flag;
     const uint32_t count = heavy[0];
-    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
-        const uint32_t b = heavy[1 + item];
-        const uint32_t s = gstart[b], e = gstart[b + 1];
-        const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
-        Xyzz acc;
-        set_infinity(acc);
-        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += MSM_THREADS) {
-            Xyzz q, r;
-            load_raw(q, partials + (size_t)(b + t) * RAW_WORDS);
-            add(r, acc, q);
-            acc = r;
+    const uint32_t K = count ? gridDim.x / count : 0;
+    if (K < 2) {
+        for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+            const uint32_t b = heavy[HEAVY_IDS + item];
+            const uint32_t s = gstart[b], e = gstart[b + 1];
+            const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
+            Xyzz acc;
+            set_infinity(acc);
+            for (uint32_t t = t0 + threadIdx.x; t <= t1; t += MSM_THREADS) {
+                Xyzz q, r;
+                load_raw(q, partials + (size_t)(b + t) * RAW_WORDS);
+                add(r, acc, q);
+                acc = r;
+            }
+            __syncthreads(); // the previous item's wave 0 is done reading sh
+            wg_tree_sum(acc, sh, MSM_THREADS, threadIdx.x);
+            if (threadIdx.x == 0) {
+                uint32_t o[32];
+                store_xyzz(o, acc);
+                st32(buckets + (size_t)b * 32, o);
+            }
         }
-        __syncthreads(); // the previous item's wave 0 is done reading sh
-        wg_tree_sum(acc, sh, MSM_THREADS, threadIdx.x);
-        if (threadIdx.x == 0) {
-            uint32_t o[32];
-            store_xyzz(o, acc);
-            st32(buckets + (size_t)b * 32, o);
-        }
+        return;
+    }
+    const uint32_t item = blockIdx.x / K, sub = blockIdx.x - item * K;
+    if (item >= count) return; // the gridDim.x - K * count workgroups left over
+    const uint32_t b = heavy[HEAVY_IDS + item];
+    const uint32_t s = gstart[b], e = gstart[b + 1];
+    const uint32_t t0 = s / ch, t1 = (e - 1) / ch, total = t1 - t0 + 1;
+    const uint32_t lo = t0 + (uint32_t)(((uint64_t)total * sub) / K), hi = t0 + (uint32_t)(((uint64_t)total * (sub + 1)) / K); // slice [lo, hi)
+    Xyzz acc;
+    set_infinity(acc);
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += MSM_THREADS) {
+        Xyzz q, r;
+        load_raw(q, partials + (size_t)(b + t) * RAW_WORDS);
+        add(r, acc, q);
+        acc = r;
+    }
+    wg_tree_sum(acc, sh, MSM_THREADS, threadIdx.x);
+    if (threadIdx.x == 0) {
+        store_raw(hpart + (size_t)blockIdx.x * RAW_WORDS, acc);
+        __threadfence(); // the slice sum is visible device-wide before this workgroup is counted as arrived
+        last_flag = (atomicAdd(&heavy[1 + item], 1u) == K - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence(); // acquire: the other workgroups' slice sums
+    set_infinity(acc);
+    if (threadIdx.x < K) load_raw(acc, hpart + (size_t)(item * K + threadIdx.x) * RAW_WORDS);
+    __syncthreads(); // wave 0 is done with sh from the first tree
+    wg_tree_sum(acc, sh, MSM_THREADS, threadIdx.x);
+    if (threadIdx.x == 0) {
+        uint32_t o[32];
+        store_xyzz(o, acc);
+        st32(buckets + (size_t)b * 32, o);
     }
 }
 
@@ -1234,8 +1341,8 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
     FqN acc = quad_zero();
     if (e > s) {
         const uint32_t t0 = s / ch, t1 = (e - 1) / ch;
-        if (t1 - t0 >= MERGE_LIGHT) { // heavy[0] = count, heavy[1..] = bucket ids
-            if (j == 0 && l == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = b;
+        if (t1 - t0 >= MERGE_LIGHT) { // heavy[0] = count, heavy[HEAVY_IDS ..] = bucket ids
+            if (j == 0 && l == 0) heavy[HEAVY_IDS + atomicAdd(&heavy[0], 1u)] = b;
             return;
         }
         // the next partial is loaded before the addition of the current one starts (a quad's partials are Q slots apart)
@@ -1472,7 +1579,7 @@ static MsmPlan make_plan(size_t n, int c)
 // came from exactly such a pair of hand-kept formulas: the fold arena was sized by a guess, (2 nw nb + 4096) points, while
 // the then per-level fold / slice chain bumped rows + columns + slices per window past it into the next page.)
 struct MsmCarve {
-    size_t digits, signs, histA, binstart, bintot, tmp_entries, gstart, totals, heavy, sorted, partials, buckets, arena, texp, end;
+    size_t digits, signs, histA, histB, binstart, bintot, tmp_entries, gstart, totals, heavy, sorted, partials, buckets, arena, texp, end;
     size_t chunks_cap;
 };
 static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
@@ -1484,12 +1591,13 @@ static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
     L.digits = p;      p += al(wmax * n * 2);
     L.signs = p;       p += al(wmax * ((n + 63) / 64) * 8);      // sign bits of 17-bit windows
     L.histA = p;       p += al(nw * P.slices * 1024 * 4);        // pass-A histogram / cursors (<= 1024 bins)
+    L.histB = p;       p += al((size_t)MSM_MAX_JOBS * 1024 * SORTB_MAX_PARTS * 128 * 4); // pass-B piece counts (table mode: <= MSM_MAX_JOBS groups)
     L.binstart = p;    p += al(nw * 1024 * 4 + 256);
     L.bintot = p;      p += al(nw * 1024 * 4 + 256);
     L.tmp_entries = p; p += al(nw * n * 4);                      // pass-A output
     L.gstart = p;      p += al((nw * P.nb + 2) * 4);             // + M at [total_buckets] + a sentinel behind it
     L.totals = p;      p += al(nw * 8 + 512);                    // totals, bases (nw + 1)
-    L.heavy = p;       p += al((nw * P.nb + 1) * 4);             // heavy-bucket queue
+    L.heavy = p;       p += al((nw * P.nb + HEAVY_IDS) * 4 + 256 + (size_t)HEAVY_WGS * RAW_WORDS * 4); // heavy-bucket queue: count, arrival counters, ids, slice sums
     L.sorted = p;      p += al(nw * n * 4);
     L.chunks_cap = (n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1;     // upper bound for any chunk length >= MIN_CHUNK
     L.partials = p;    p += al((nw * P.nb + L.chunks_cap) * RAW_WORDS * 4);
@@ -1654,6 +1762,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     void* digits = (void*)(p + LY.digits);
     unsigned long long* signs = (unsigned long long*)(p + LY.signs);
     uint32_t* histA = (uint32_t*)(p + LY.histA);
+    uint32_t* histB = (uint32_t*)(p + LY.histB);
     uint32_t* binstart = (uint32_t*)(p + LY.binstart);
     uint32_t* bintot = (uint32_t*)(p + LY.bintot);
     uint32_t* tmp_entries = (uint32_t*)(p + LY.tmp_entries);
@@ -1720,8 +1829,13 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     else sortA_scatter_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
                                                                    slice_len, (uint32_t)wb, wpg, idx_stride, P.W, row_i0, row_i1, blo, bcnt);
     if (!(staged & 1)) sortB_kernel<<<dim3(sort_bins, G), table ? SORT_THREADS : 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
-    else if (table) sortB_staged_kernel<SORT_THREADS><<<dim3(sort_bins, G), SORT_THREADS, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
-    else sortB_staged_kernel<256><<<dim3(sort_bins, G), 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb);
+    else if (table) {
+        // large MSMs: eight pieces per bin (one more launch, ~8 us on the front; small MSMs are chains of dependent launches and keep one)
+        static const int parts_env = [] { const char* e = getenv("BBGPU_SORTB_PARTS"); return e ? std::min((int)SORTB_MAX_PARTS, std::max(1, atoi(e))) : 0; }(); // tuning knob
+        const uint32_t parts = parts_env ? (uint32_t)parts_env : (((uint64_t)n * nw1 >= ((uint64_t)1 << 21) && G <= MSM_MAX_JOBS) ? SORTB_MAX_PARTS : 1u);
+        if (parts > 1) sortB_count_kernel<SORT_THREADS><<<dim3(sort_bins, G, parts), SORT_THREADS, 0, st>>>(tmp_entries, binstart, bases, histB, sort_bins, parts);
+        sortB_staged_kernel<SORT_THREADS><<<dim3(sort_bins, G, parts), SORT_THREADS, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb, histB, parts);
+    } else sortB_staged_kernel<256><<<dim3(sort_bins, G), 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb, nullptr, 1u);
     if (tm_acc) HIPCHK(hipEventRecord(ev[2], st));
     // K4 + K4m
     const uint32_t total_buckets = G * P.nb;
@@ -1751,7 +1865,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     } else {
         S.acc_seq = 0;
     }
-    if (!fold) HIPCHK(hipMemsetAsync(heavy, 0, 4, st));
+    if (!fold) HIPCHK(hipMemsetAsync(heavy, 0, HEAVY_IDS * 4, st));
     static const bool quad_tail = [] { const char* e = getenv("BBGPU_QUAD_TAIL"); return !e || atoi(e) != 0; }(); // 0: one point per lane (round 1)
     static const uint64_t quad_merge_max_entries = [] { const char* e = getenv("BBGPU_QUAD_MERGE_MAX_LOG"); return (uint64_t)1 << (e ? std::min(30, std::max(10, atoi(e))) : 21); }(); // tuning knob
     static const int quad_merge = [] { const char* e = getenv("BBGPU_QUAD_MERGE"); return e ? atoi(e) : 1; }(); // tuning knob: 0 off, 1 on, 2.. = 1 + forced logQ
@@ -1769,7 +1883,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     } else
     msm_merge_kernel<<<(uint32_t)((((uint64_t)merge_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
                                                                                                                      blo, blo + merge_buckets, ch, merge_light, logG);
-    msm_merge_heavy_kernel<<<256, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch);
+    msm_merge_heavy_kernel<<<HEAVY_WGS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch, heavy + (((size_t)nw * P.nb + HEAVY_IDS + 63) & ~(size_t)63));
     if (tm) HIPCHK(hipEventRecord(ev[4], st));
 
     // K5: bucket b = hi * 2^l + lo carries weight b + 1:
