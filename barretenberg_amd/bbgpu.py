@@ -37,11 +37,11 @@ NTT_KINDS = {
 
 C_ABI_SYMBOLS = [
     "bbgpu_init", "bbgpu_shutdown", "bbgpu_device_count", "bbgpu_last_error", "bbgpu_version", "bbgpu_ntt",
-    "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_set_precompute",
+    "bbgpu_ntt_device", "bbgpu_ntt_device_batch", "bbgpu_srs_register", "bbgpu_srs_release", "bbgpu_srs_generate", "bbgpu_srs_generate_range", "bbgpu_set_precompute",
     "bbgpu_srs_num_windows", "bbgpu_transcript_read_g1", "bbgpu_transcript_write", "bbgpu_msm_g1", "bbgpu_msm_g1_plain",
     "bbgpu_msm_g1_batch", "bbgpu_msm_num_windows", "bbgpu_msm_g1_device", "bbgpu_msm_g1_device_async", "bbgpu_msm_g1_device_rows_async", "bbgpu_msm_g1_device_buckets_async", "bbgpu_srs_has_window_tables", "bbgpu_msm_g1_wait",
     "bbgpu_msm_g1_device_batch_async", "bbgpu_msm_g1_batch_wait",
-    "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_set_table_share", "bbgpu_selftest_field", "bbgpu_selftest_g1",
+    "bbgpu_g1_sum", "bbgpu_last_timing", "bbgpu_set_host_thresholds", "bbgpu_srs_cache_stats", "bbgpu_set_table_share", "bbgpu_set_point_share", "bbgpu_selftest_field", "bbgpu_selftest_g1",
     "bbgpu_set_timing",
     "bbgpu_fr_evaluate_device", "bbgpu_fr_batch_invert_device", "bbgpu_fr_product_scan_device", "bbgpu_fr_mul_device",
     "bbgpu_kate_opening_device", "bbgpu_lagrange_l1_fft_device", "bbgpu_divide_by_pseudo_vanishing_device",
@@ -95,6 +95,7 @@ class BbGpu:
         L.bbgpu_ntt_device_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
         L.bbgpu_srs_register.argtypes = [u64p, C.c_size_t]
         L.bbgpu_srs_generate.argtypes = [u64p, C.c_size_t, u64p]
+        L.bbgpu_srs_generate_range.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
         L.bbgpu_msm_g1.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1_plain.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1_batch.argtypes = [C.POINTER(MsmJob), C.c_size_t]
@@ -204,10 +205,11 @@ class BbGpu:
     def srs_register(self, points_endo_table):
         return self._chk(self.lib.bbgpu_srs_register(_ptr(points_endo_table), points_endo_table.shape[0] // 2))
 
-    def srs_generate(self, x_mont, n, want_host_table=False):
+    def srs_generate(self, x_mont, n, want_host_table=False, first=0):
+        """resident points x^(first + i) G, i < n (first > 0: the slice of a rank of a point-range split)"""
         table = np.zeros((2 * n, 8), dtype=np.uint64) if want_host_table else None
-        h = self._chk(self.lib.bbgpu_srs_generate(_ptr(np.ascontiguousarray(x_mont, dtype=np.uint64)), n,
-                                                  _ptr(table) if want_host_table else None))
+        h = self._chk(self.lib.bbgpu_srs_generate_range(_ptr(np.ascontiguousarray(x_mont, dtype=np.uint64)), first, n,
+                                                        _ptr(table) if want_host_table else None))
         return (h, table) if want_host_table else h
 
     def read_transcript(self, path, degree):
@@ -266,6 +268,10 @@ class BbGpu:
     def set_table_share(self, rank, world):
         """tables registered from now on keep only the digit windows rank `rank` of `world` touches (multi-GPU row split); (0, 1): full tables"""
         self.lib.bbgpu_set_table_share(int(rank), int(world))
+
+    def set_point_share(self, world):
+        """tables registered from now on are a rank's n / world points of a larger MSM (point-range split): window size as for the whole; 1: default"""
+        self.lib.bbgpu_set_point_share(int(world))
 
     def set_precompute(self, on=True):
         self.lib.bbgpu_set_precompute(1 if on else 0)

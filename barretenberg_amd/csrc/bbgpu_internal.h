@@ -40,6 +40,9 @@ struct MsmSlot {
     size_t n = 0;
     uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0, jobs = 1;
     uint64_t acc_seq = 0; // position of this MSM's accumulation in the process-wide sequence of timed accumulations (0 = none)
+    // set by the caller before an issue: other MSMs are in flight, so this one is paced by the instructions it issues, not by its dependent chain
+    // (msm_issue_batch then takes longer chunks and the two-step row / column sums)
+    bool throughput = false;
     void release();
 };
 int msm_choose_c(size_t n);
@@ -57,7 +60,7 @@ int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing);
 int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, int w_begin, int w_end, uint32_t** d_alloc_out, uint32_t** d_tab_out, hipStream_t st);
 int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_table, size_t n, uint32_t** d_srs_out, hipStream_t st, size_t stride_bytes = 128);
-int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);
+int srs_generate(const uint64_t* x_mont256, size_t first, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);
 
 // capi.hip: the caller's host buffers cross the link through the library's OWN pinned buffers (see host_to_device)
 int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st);

@@ -87,6 +87,7 @@ struct Context {
     int host_ntt_max = 16;
     bool host_env_read = false;
     int share_rank = 0, share_world = 1; // window share of the tables built from now on (bbgpu_set_table_share)
+    int point_world = 1;                 // tables built from now on hold 1 / point_world of the points of a larger MSM (bbgpu_set_point_share)
     // Workspaces shared by every caller (NTT scratch, polynomial temporaries): users on different streams are chained by this event
     hipEvent_t shared_done = nullptr;
     hipStream_t shared_last = nullptr;
@@ -312,15 +313,18 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
         e.row_hash.resize(n);
         for (size_t i = 0; i < n; i++) e.row_hash[i] = hash_row(host_ptr + i * 16);
     }
-    int c = msm_choose_c(n);
+    // a rank's slice of a point-range split takes the window size of the whole MSM: measured on 1/4 and 1/8 slices of 2^20 points, four in flight,
+    // 15-bit windows 0.356 / 0.189 ms per step, 17-bit 0.334 / 0.188 (16-bit at 1/8: 0.182) -- tools/slice_ab.py
+    const size_t n_for_c = n * (size_t)g_ctx.point_world;
+    int c = msm_choose_c(n_for_c);
     // with tables every window feeds one shared bucket set, so wider windows only cost bucket-reduction depth while each one
     // saved is n fewer mixed additions: measured on the resident prover (tools/plonk_bench.py), 2^16 gates 3.58 ms at c = 12,
     // 3.40 / 3.54 / 3.36 / 3.40 at c = 13 / 14 / 15 / 16; 2^18 gates 7.51 ms at c = 14, 7.19 at c = 15, 7.20 at c = 16
-    if (n >= ((size_t)1 << 16) && c < 15) c = 15;
+    if (n_for_c >= ((size_t)1 << 16) && c < 15) c = 15;
     // 17-bit windows (15 instead of 16 of them, signed digits up to +-2^16 kept as uint16 magnitude + sign bit, 2^16 buckets): one n-th fewer mixed additions.
     // Measured: single 2^20 MSM 1.611 -> 1.546 ms, two in flight 1.345 -> 1.287 ms/step (-4.3 %); prover 2^19 gates 11.89 -> 11.51 ms,
     // 2^20 gates 22.1-22.8 -> 22.0 ms; 2^18 gates unchanged (6.8 ms), so smaller tables keep c = 15
-    if (n >= ((size_t)1 << 19)) c = 17;
+    if (n_for_c >= ((size_t)1 << 19)) c = 17;
     if (const char* ev = getenv("BBGPU_TABLE_C")) c = std::min(17, std::max(4, atoi(ev))); // tuning knob: window size of the tables
     const int W = msm_num_windows(c);
     const bool want_tab = g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24);
@@ -382,8 +386,13 @@ int pick_slot()
 {
     int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1 };
     for (int k = 2; k < Context::NSLOT; k++) order[k] = k;
+    bool others = false; // another MSM in flight: the one about to be issued shares the chip (MsmSlot::throughput)
+    for (int k = 0; k < Context::NSLOT; k++) others = others || g_ctx.slot[k].pending;
     for (int k = 0; k < Context::NSLOT; k++)
-        if (!g_ctx.slot[order[k]].pending) return order[k];
+        if (!g_ctx.slot[order[k]].pending) {
+            g_ctx.slot[order[k]].throughput = others;
+            return order[k];
+        }
     set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
     return -1;
 }
@@ -926,16 +935,20 @@ int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n)
     return add_srs(points_endo_table, n, d, false);
 }
 
-int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out)
+int bbgpu_srs_generate_range(const uint64_t* x_mont, size_t first, size_t n, uint64_t* host_endo_table_out)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     int rc = ensure_init();
     if (rc) return rc;
-    if (!x_mont || n == 0) return BBGPU_ERR_ARG;
+    if (!x_mont || n == 0 || first > ((size_t)1 << 31) || n > ((size_t)1 << 31)) return BBGPU_ERR_ARG;
     uint32_t* d = nullptr;
-    rc = srs_generate(x_mont, n, &d, host_endo_table_out, g_ctx.stream);
+    rc = srs_generate(x_mont, first, n, &d, host_endo_table_out, g_ctx.stream);
     if (rc) return rc;
     return add_srs(host_endo_table_out, n, d, false);
+}
+int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out)
+{
+    return bbgpu_srs_generate_range(x_mont, 0, n, host_endo_table_out);
 }
 
 // io.hpp:36-182 restated for the G1 part: 28-byte manifest of seven big-endian uint32 (fields 5 = num_g1_points), then points as
@@ -1108,6 +1121,14 @@ void bbgpu_set_table_share(int rank, int world)
     if (world < 1 || rank < 0 || rank >= world) { rank = 0; world = 1; }
     g_ctx.share_rank = rank;
     g_ctx.share_world = world;
+}
+
+// Multi-GPU, the other split: a rank holds n / world POINTS of a larger MSM as its own SRS (all digit windows of them) and its MSM over the matching
+// scalars is its partial sum.  Tables registered from now on pick their window size as the whole MSM would.
+void bbgpu_set_point_share(int world)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    g_ctx.point_world = world >= 1 && world <= 1024 ? world : 1;
 }
 
 void bbgpu_set_precompute(int enabled)

@@ -221,14 +221,14 @@ __device__ __forceinline__ Fe<Fq, 1, 2> fq_inverse(const Fe<Fq, 1, 2>& a)
     const uint64_t e[4] = { Fq::P64[0] - 2, Fq::P64[1], Fq::P64[2], Fq::P64[3] };
     return pow_u256<Fq>(a, e);
 }
-// srs[i] = x^i * G, affine canonical Montgomery-261
-__global__ void srs_gen_points_kernel(const uint32_t* __restrict__ tab, Limbs9 x261, uint32_t* __restrict__ srs, uint32_t n)
+// srs[i] = x^(first + i) * G, affine canonical Montgomery-261
+__global__ void srs_gen_points_kernel(const uint32_t* __restrict__ tab, Limbs9 x261, uint32_t* __restrict__ srs, uint32_t n, uint32_t first)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // s = x^i in Fr (Montgomery-261), then plain canonical
+    // s = x^(first + i) in Fr (Montgomery-261), then plain canonical
     Fe<Fr, 1, 2> s = fe_one<Fr>(), b = fe_from<Fr>(x261.d);
-    for (uint32_t e = i; e; e >>= 1) {
+    for (uint32_t e = first + i; e; e >>= 1) {
         if (e & 1) s = mul(s, b);
         b = sqr(b);
     }
@@ -1288,7 +1288,7 @@ __device__ __forceinline__ FqN quad_zero()
     return FqN(fe_zero<Fq>());
 }
 // acc: this lane's coordinate of its quad's partial sum; returns the workgroup's sum in quad 0 of wave 0 (lanes 0..3)
-__device__ __forceinline__ FqN block_quad_sum(FqN acc, uint32_t* sh /* [QFOLD_T / 64][4][NL] */, uint32_t t)
+template <int T = QFOLD_T> __device__ __forceinline__ FqN block_quad_sum(FqN acc, uint32_t* sh /* [T / 64][4][NL] */, uint32_t t)
 {
     const uint32_t l = t & 3, lane = t & 63, wave = t >> 6, qd = lane >> 2;
     for (uint32_t off = 8; off >= 1; off >>= 1) {
@@ -1297,13 +1297,14 @@ __device__ __forceinline__ FqN block_quad_sum(FqN acc, uint32_t* sh /* [QFOLD_T 
         for (int i = 0; i < NL; i++) o.d[i] = __shfl_down(acc.d[i], off * 4);
         if (qd < off) acc = quad_add(acc, o, l);
     }
+    if constexpr (T == 64) return acc; // one wave: the tree above was all of it
     if (lane < 4) {
 #pragma unroll
         for (int i = 0; i < NL; i++) sh[(wave * 4 + l) * NL + i] = acc.d[i];
     }
     __syncthreads();
     if (wave == 0) {
-        constexpr uint32_t NW = QFOLD_T / 64;
+        constexpr uint32_t NW = T / 64;
         acc = quad_zero();
         if (qd < NW) {
 #pragma unroll
@@ -1414,6 +1415,79 @@ __global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4,
         quad_store8((row ? R + ((size_t)g * H + idx) * 32 : Cc + ((size_t)g * L + idx) * 32) + 8 * l, w);
     }
 }
+// K5 for large bucket sets, in two steps that leave no lane idle.  The one-launch form above spends half of its issue slots on tree levels with
+// most quads masked off (2^16 buckets: 15.4 k wave-level quad additions for 131 k useful ones = 53 %; 20.6 M VALU instructions, the largest
+// item of an MSM after the accumulation and the one a 1/N share of a multi-GPU MSM pays in full).  Step 1: ONE LANE per segment of ROWCOL_SEG
+// buckets of a row (lanes [0, H L / SEG)) or of a column (the L H / SEG lanes after them) adds them with the plain addition (3,700
+// lane-instructions against 4 x 1,350 for a quad): 3 dependent additions, every lane busy.  Step 2: one wave per row / column sums its
+// L / SEG (H / SEG) segment sums as 16 quads (<= 3 sequential + 4 tree levels).  2^16 buckets: 5.7 M + 4.5 M instructions for the same chain length.
+constexpr uint32_t ROWCOL_SEG = 4;
+__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_seg_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ segs, uint32_t H, uint32_t L,
+                                                                                                                uint32_t* __restrict__ zero_out, uint32_t zero_words)
+{
+    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    const uint32_t g = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x, nb = H * L;
+    if (zero_out) { // the export slots (infinity = all zero) are cleared here instead of by a fill launch
+        const uint32_t gid = g * gridDim.x * blockDim.x + t, all = gridDim.y * gridDim.x * blockDim.x;
+        for (uint32_t i = gid; i < zero_words; i += all) zero_out[i] = 0;
+    }
+    const uint32_t row_lanes = H * (L / ROWCOL_SEG), col_lanes = L * (H / ROWCOL_SEG);
+    if (t >= row_lanes + col_lanes) return;
+    // rows: lane t = (row, s) sums buckets row * L + s + j * (L / SEG); columns: lane u = (s, col) sums rows s + j * (H / SEG) of column col.
+    // Either way neighbouring lanes read neighbouring buckets.  Segment sums of row r: segs[r * (L / SEG) + s]; of column c: behind the rows, [c * (H / SEG) + s].
+    size_t b, step, out;
+    if (t < row_lanes) {
+        const uint32_t per = L / ROWCOL_SEG, r = t / per, sidx = t - r * per;
+        b = (size_t)r * L + sidx;
+        step = per;
+        out = t;
+    } else {
+        const uint32_t u = t - row_lanes, per = H / ROWCOL_SEG, sidx = u / L, c = u - sidx * L;
+        b = (size_t)sidx * L + c;
+        step = (size_t)per * L;
+        out = (size_t)row_lanes + (size_t)c * per + sidx;
+    }
+    const uint32_t* src = buckets + ((size_t)g * nb + b) * 32;
+    Xyzz acc;
+    {
+        uint32_t w[32];
+        ld32(src, w);
+        load_xyzz(acc, w);
+    }
+    for (uint32_t j = 1; j < ROWCOL_SEG; j++) {
+        uint32_t w[32];
+        ld32(src + j * step * 32, w);
+        Xyzz q, r;
+        load_xyzz(q, w);
+        add(r, acc, q);
+        acc = r;
+    }
+    uint32_t o[32];
+    store_xyzz(o, acc);
+    st32(segs + ((size_t)g * (row_lanes + col_lanes) + out) * 32, o);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_segsum_quad_kernel(const uint32_t* __restrict__ segs, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc, uint32_t H, uint32_t L)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t g = blockIdx.y, t = threadIdx.x, l = t & 3, quad = t >> 2;
+    const uint32_t row_lanes = H * (L / ROWCOL_SEG), col_lanes = L * (H / ROWCOL_SEG);
+    const bool row = blockIdx.x < H;
+    const uint32_t idx = row ? blockIdx.x : blockIdx.x - H, count = row ? L / ROWCOL_SEG : H / ROWCOL_SEG;
+    const uint32_t* src = segs + ((size_t)g * (row_lanes + col_lanes) + (row ? (size_t)idx * count : (size_t)row_lanes + (size_t)idx * count)) * 32;
+    FqN acc = quad_zero();
+    bool first = true;
+    for (uint32_t e = quad; e < count; e += 16) { // quad-uniform trip count
+        const FqN v = quad_load(src + (size_t)e * 32, l);
+        acc = first ? v : quad_add(acc, v, l);
+        first = false;
+    }
+    acc = block_quad_sum<64>(acc, nullptr, t);
+    if (t < 4) {
+        uint32_t w[8];
+        to_canonical(acc, w);
+        quad_store8((row ? R + ((size_t)g * H + idx) * 32 : Cc + ((size_t)g * L + idx) * 32) + 8 * l, w);
+    }
+}
 __global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_final_quad_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
                                                                  uint32_t hbits, uint32_t lbits)
 {
@@ -1517,6 +1591,11 @@ static uint32_t acc_capacity_lanes()
 // (small MSMs are latency-bound: a lane's chain of `ch` dependent mixed additions is the critical path, ~5 us each)
 constexpr uint32_t MIN_CHUNK = 8;
 static uint32_t chunk_len_m(uint64_t m);
+static bool chunk_forced()
+{
+    static const bool f = getenv("BBGPU_CHUNK") != nullptr || getenv("BBGPU_ACC_WAVES") != nullptr;
+    return f;
+}
 static uint32_t chunk_len(size_t n, uint32_t nw)
 {
     return chunk_len_m((uint64_t)n * nw);
@@ -1556,6 +1635,16 @@ static size_t arena_points(const MsmPlan& P, uint32_t nw)
     const size_t H = (size_t)1 << P.hbits, L = (size_t)1 << P.lbits;
     return (size_t)nw * (H + L) + 64; // row sums + column sums per bucket set
 }
+// two-step row / column sums (msm_rowcol_seg_kernel): bucket sets of 2^15 and more
+static bool rowcol_two_step(const MsmPlan& P)
+{
+    return P.hbits + P.lbits >= 15;
+}
+static size_t seg_points(const MsmPlan& P, uint32_t nw)
+{
+    const size_t H = (size_t)1 << P.hbits, L = (size_t)1 << P.lbits;
+    return rowcol_two_step(P) ? (size_t)nw * 2 * (H * L / ROWCOL_SEG) : 0;
+}
 static MsmPlan make_plan(size_t n, int c)
 {
     MsmPlan P;
@@ -1579,7 +1668,7 @@ static MsmPlan make_plan(size_t n, int c)
 // came from exactly such a pair of hand-kept formulas: the fold arena was sized by a guess, (2 nw nb + 4096) points, while
 // the then per-level fold / slice chain bumped rows + columns + slices per window past it into the next page.)
 struct MsmCarve {
-    size_t digits, signs, histA, histB, binstart, bintot, tmp_entries, gstart, totals, heavy, sorted, partials, buckets, arena, texp, end;
+    size_t digits, signs, histA, histB, binstart, bintot, tmp_entries, gstart, totals, heavy, sorted, partials, buckets, arena, segs, texp, end;
     size_t chunks_cap;
 };
 static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
@@ -1603,6 +1692,7 @@ static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
     L.partials = p;    p += al((nw * P.nb + L.chunks_cap) * RAW_WORDS * 4);
     L.buckets = p;     p += al(nw * P.nb * 128);
     L.arena = p;       p += al(arena_points(P, (uint32_t)nw) * 128); // row sums + column sums
+    L.segs = p;        p += al(seg_points(P, (uint32_t)nw) * 128);   // segment sums of the two-step row / column sums (large bucket sets)
     L.texp = p;        p += al(nw * 64 * 128);                   // exported T points
     L.end = p;
     return L;
@@ -1705,6 +1795,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         set_error("MSM of %zu points: at most 2^24 points per call", n);
         return BBGPU_ERR_SIZE;
     }
+    const bool hint = S.throughput; // one-shot: the synchronous entry points use slots 0 / 1 without going through pick_slot()
+    S.throughput = false;
     const bool table = d_tab != nullptr;
     const int c = table ? tab_c : msm_choose_c(n);
     const MsmPlan P = make_plan(n, c);
@@ -1842,7 +1934,16 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     // a bucket-range share expects its fraction of the entries (uniform digits); the grid below still covers the worst case
     const uint64_t m_expected = bshare ? std::max<uint64_t>(1, (uint64_t)n * nw * bcnt / P.nb) : (uint64_t)n * nw;
     const uint32_t merge_buckets = bshare ? bcnt : total_buckets; // buckets the merge and the folds visit
-    const uint32_t ch = bshare ? chunk_len_m(m_expected) : chunk_len(n, nw);
+    // Other MSMs in flight (S.throughput): the chip is shared and what counts is the instructions this one issues.  Lanes with fewer than ~20 entries
+    // pay their prologue (start-bucket search, first row) and their partial sums (one per lane and bucket touched: the merge's work) for little;
+    // measured on 1/8 shares of a 2^20 MSM, four in flight: chunks of 10 (the latency choice) 0.202 ms per step, 15: 0.191, 20: 0.181, 25: 0.190, 30: 0.183;
+    // 2^16 points, three in flight: 0.126 -> 0.118 ms (tools/point_share_ab.py, tools/msm_ab.py with BBGPU_CHUNK).
+    static const int tp_env = [] { const char* e = getenv("BBGPU_THROUGHPUT"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force the latency / throughput choices
+    const bool tp = (tp_env < 0 ? hint : tp_env != 0) && jobs == 1;
+    constexpr uint32_t TP_MIN_CHUNK = 20;
+    uint32_t ch = bshare ? chunk_len_m(m_expected) : chunk_len(n, nw);
+    if (tp && ch < TP_MIN_CHUNK && !chunk_forced()) // ... as long as one workgroup per CU is left (a 2-of-17-window share of 2^16 points, 131 k entries: chunks of 20 0.091 ms per step, of 8 0.072)
+        ch = std::max(ch, std::min<uint32_t>(TP_MIN_CHUNK, (uint32_t)(m_expected / (acc_capacity_lanes() / acc_wg_per_cu()))));
     // merge: 2^logG lanes per bucket, sized for the expected number of partials per bucket (~ entries / (buckets * ch) + 1);
     // a bucket cut into more than 8 partials per lane of its group is queued for the workgroup-per-bucket kernel
     // -- but no wider than what fills the chip once (~2^16 lanes): beyond that the extra lanes only add issue work
@@ -1896,6 +1997,13 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         uint32_t* Cc = scratch + (size_t)G * H * 32;
         uint32_t* dest = fold ? (uint32_t*)ws.h_out : texp; // pinned host memory is device-accessible under the same pointer
         const uint32_t zero_words = G * 64 * 32;
+        static const bool two_step_env = [] { const char* e = getenv("BBGPU_ROWCOL_TWO_STEP"); return !e || atoi(e) != 0; }(); // 0: the one-launch quad form for every size
+        if (quad_tail && two_step_env && !bshare && rowcol_two_step(P) && (tp || jobs > 1)) { // alone, the one-launch form is ~20 us shorter
+            uint32_t* segs = (uint32_t*)(p + LY.segs);
+            const uint32_t seg_lanes = 2 * (H * L / ROWCOL_SEG);
+            msm_rowcol_seg_kernel<<<dim3((seg_lanes + MSM_THREADS - 1) / MSM_THREADS, G), MSM_THREADS, 0, st>>>(buckets, segs, H, L, fold ? dest : nullptr, zero_words);
+            msm_segsum_quad_kernel<<<dim3(H + L, G), 64, 0, st>>>(segs, Rr, Cc, H, L);
+        } else
         if (quad_tail) msm_rowcol_quad_kernel<<<dim3((bshare ? brow1 - brow0 : H) + L, G), QFOLD_T, 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words, bshare ? brow0 : 0u,
                                                                                                    bshare ? brow1 - brow0 : H);
         else msm_rowcol_kernel<<<dim3(H + L, G), std::max(H, L), 0, st>>>(buckets, Rr, Cc, H, L, fold ? dest : nullptr, zero_words);
@@ -2036,7 +2144,7 @@ int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, int
     return BBGPU_OK;
 }
 
-int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st)
+int srs_generate(const uint64_t* x_mont256, size_t first, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st)
 {
     uint32_t* d_tab = nullptr;
     uint32_t* d_srs = nullptr;
@@ -2052,7 +2160,7 @@ int srs_generate(const uint64_t* x_mont256, size_t n, uint32_t** d_srs_out, uint
     Fe<Fr, 1, 6> xc = unpack<Fr>(cw);
     Limbs9 xl;
     for (int i = 0; i < NL; i++) xl.d[i] = xc.d[i];
-    srs_gen_points_kernel<<<(uint32_t)((n + 63) / 64), 64, 0, st>>>(d_tab, xl, d_srs, (uint32_t)n);
+    srs_gen_points_kernel<<<(uint32_t)((n + 63) / 64), 64, 0, st>>>(d_tab, xl, d_srs, (uint32_t)n, (uint32_t)first);
     HIPCHK(hipGetLastError());
     if (host_table_out) {
         uint32_t* d_exp = nullptr;

@@ -336,9 +336,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
     ap.add_argument("--probe", action="store_true", help="no GPU work: form the process group of the N ranks, report who is there, exit (launch check)")
-    ap.add_argument("--shard", default="rows", choices=("buckets", "rows", "windows"),
-                    help="N > 1: how one MSM is split over the ranks (buckets: every rank reduces 1/N of the bucket range over all windows; "
-                         "rows: 1/N of the (window, point) table rows; windows: whole digit windows)")
+    ap.add_argument("--shard", default="points", choices=("points", "buckets", "rows", "windows"),
+                    help="N > 1: how one MSM is split over the ranks (points: rank r holds points and scalars [n r / N, n (r + 1) / N) with all their digit windows -- "
+                         "the reference's own per-thread slicing, and the one split where the digit kernel's work divides by N too; "
+                         "rows: 1/N of the (window, point) table rows, all scalars on every rank; buckets: every rank reduces 1/N of the bucket range over all windows; "
+                         "windows: whole digit windows)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -399,31 +401,38 @@ def main():
     single = (rank == 0 and world == 1)
     cpu_leg = single and not args.no_cpu_baseline  # the CPU reference is timed at N = 1 only
     host_legs = single and not args.no_boundary   # boundary-inclusive legs need the host copy of the point table
-    if world > 1 and not args.no_window_tables and args.shard != "buckets":
+    by_points = world > 1 and args.shard == "points" and not args.no_window_tables
+    pt0, pt1 = (n * rank // world, n * (rank + 1) // world) if by_points else (0, n)  # this rank's point range
+    if world > 1 and not args.no_window_tables and args.shard in ("rows", "windows"):
         G.set_table_share(rank, world)  # this rank's 1/N of the (window, point) rows touches ceil(W / N) + 1 digit windows: only those are built and kept
+    if by_points:
+        G.set_point_share(world)        # the slice's tables take the window size of the whole MSM
     torch.cuda.synchronize()
     t_srs0 = time.perf_counter()
     if cpu_leg or host_legs:
         srs, table = G.srs_generate(x_secret, n, want_host_table=True)
     else:
-        srs, table = G.srs_generate(x_secret, n), None
+        srs, table = G.srs_generate(x_secret, pt1 - pt0, first=pt0), None  # a point-range rank generates and keeps its slice only
     torch.cuda.synchronize()
     srs_setup_ms = (time.perf_counter() - t_srs0) * 1e3  # one-time: points generated, window tables built (and the host copy written when asked for)
     G.set_table_share(0, 1)
+    G.set_point_share(1)
     d_scalars = to_montgomery_on_device(G, raw_scalars(n, SPLITMIX_GAMMA), dev)
     scalars = d_scalars.cpu().numpy().view(np.uint64) if (cpu_leg or host_legs) else None
-    W = G.srs_num_windows(srs, n)
+    W = G.srs_num_windows(srs, pt1 - pt0)
     wb, we = W * rank // world, W * (rank + 1) // world
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the 96-byte partial sums are exchanged
 
     # with window tables (one shared bucket set) the W * n (window, point) pairs split at ANY row, so every rank takes exactly 1/N of them
     # even when N does not divide W (15 windows of 17 bits at 2^20); without tables the split follows whole windows
-    wb_tab, we_tab = (W * rank // world, -(-W * (rank + 1) // world)) if (world > 1 and args.shard != "buckets") else (0, W)  # digit windows whose tables this rank keeps
+    wb_tab, we_tab = (W * rank // world, -(-W * (rank + 1) // world)) if (world > 1 and args.shard in ("rows", "windows")) else (0, W)  # digit windows whose tables this rank keeps
     by_buckets = world > 1 and args.shard == "buckets" and G.srs_has_window_tables(srs)  # every rank over all windows and points, 1 / N of the bucket range
     by_rows = world > 1 and args.shard == "rows" and G.srs_has_window_tables(srs)
     rows = (W * n * rank // world, W * n * (rank + 1) // world)
 
     def issue():
+        if by_points:
+            return G.msm_device_async(srs, d_scalars.data_ptr() + pt0 * 32, pt1 - pt0) if pt1 > pt0 else None
         if by_buckets:
             return G.msm_device_buckets_async(srs, d_scalars.data_ptr(), n, rank, world)
         if by_rows:
@@ -497,7 +506,7 @@ def main():
     sharded_ok = None
     if world > 1:
         srs_full = G.srs_generate(x_secret, n)  # complete tables, for this check only
-        full = G.msm_device(srs_full, d_scalars.data_ptr(), n, 0, 0, W)
+        full = G.msm_device(srs_full, d_scalars.data_ptr(), n)
         G.srs_release(srs_full)
         sharded_ok = bool(np.array_equal(full, res))
 
@@ -506,7 +515,11 @@ def main():
     stage = np.zeros(7)
     reps = 5
     for _ in range(reps):
-        if by_buckets:
+        if by_points:
+            if pt1 > pt0:
+                G.msm_device(srs, d_scalars.data_ptr() + pt0 * 32, pt1 - pt0)
+                stage += np.array(G.last_timing()[:7])
+        elif by_buckets:
             G.msm_wait(G.msm_device_buckets_async(srs, d_scalars.data_ptr(), n, rank, world))
             stage += np.array(G.last_timing()[:7])
         elif by_rows:
@@ -660,7 +673,7 @@ def main():
                     rocprof_spacing_ms = float(m.group(1))
                     rocprof_frac = alg_bytes / (rocprof_spacing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 break
-        share_adds = (W * n // world) if by_buckets else (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation (expected, for bucket shares)
+        share_adds = (W * (pt1 - pt0)) if by_points else (W * n // world) if by_buckets else (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation (expected, for bucket shares)
         # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition (round-3 loop: 2,142 instructions in the hot
         # path + ~85 in the bucket-start block that ~1 trip in 4 runs) = 738 v_mad_u64_u32 with two VGPR factors + 729 with an SGPR factor
         # + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 194 v_and_b32 + ~275 other VALU, priced at the measured chip-wide issue rates of
@@ -689,9 +702,9 @@ def main():
             "config": {"workload": "2^%d-point BN254 G1 MSM, splitmix64 scalars (< 2^252, Montgomery form) vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
                        "one_time_costs": {"note": "paid once per SRS / per transform size, excluded from every timed figure",
                                           "srs_setup_ms": srs_setup_ms, "srs_setup_what": "bbgpu_srs_generate: points + window tables" + (" + host copy of the point table" if table is not None else ""),
-                                          "srs_table_bytes": int(min(we_tab - wb_tab, W) * n * 64) if not args.no_window_tables and W * n <= (1 << 24) else 0, "srs_points_bytes": n * 64,
+                                          "srs_table_bytes": int(min(we_tab - wb_tab, W) * (pt1 - pt0) * 64) if not args.no_window_tables and W * n <= (1 << 24) else 0, "srs_points_bytes": (pt1 - pt0) * 64,
                                           "ntt_table_bytes": int(4 * n * 32) if n <= (1 << 22) else None},
-                       "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by bucket range (all windows and points, 1 / N of the buckets each)" if by_buckets else "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
+                       "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by point range (n / N points and scalars each, all windows)" if by_points else "by bucket range (all windows and points, 1 / N of the buckets each)" if by_buckets else "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
                        "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},
             "stage_ms": {"device_total": float(stage[0]), "digits": float(stage[1]), "sort": float(stage[2]), "accumulate": float(stage[3]),
                          "merge": float(stage[4]), "bucket_folds": float(stage[5]), "slices_collect": float(stage[6]),

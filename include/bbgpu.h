@@ -94,6 +94,11 @@ void bbgpu_set_precompute(int enabled);
  * shares inside that range): ceil(W / world) + 1 windows instead of W.  Asking such a table for other windows returns BBGPU_ERR_STATE.
  * (0, 1) restores full tables. */
 void bbgpu_set_table_share(int rank, int world);
+/* Multi-GPU, split by POINT range (the slicing of scalar_multiplication.cpp:703-738 -- ranges of points per thread, summed at the end -- at the
+ * multi-GPU level): rank r of N registers points [n r / N, n (r + 1) / N) as its own SRS and runs bbgpu_msm_g1_device(_async) over the matching
+ * scalars; the N results add up to the MSM (bbgpu_g1_sum).  After this call, tables registered pick the window size the WHOLE MSM of
+ * world * n points would (17 bits from 2^19 points on) instead of the one for n points.  1 restores the default. */
+void bbgpu_set_point_share(int world);
 /* number of digit windows an MSM of n points against this table is split into (use this, not bbgpu_msm_num_windows, to
  * shard windows over ranks: a table carries the window size it was built for) */
 int bbgpu_srs_num_windows(int srs_handle, size_t n);
@@ -113,6 +118,9 @@ int bbgpu_transcript_write(const char* path, const uint64_t* points_endo_table, 
 /* device-side generation of the synthetic SRS x^i * G, i < n, straight into a resident table; optionally also written
  * back to the host as the reference-format 2n endo table (may be NULL).  Stands in for the missing srs_db/transcript.dat */
 int bbgpu_srs_generate(const uint64_t* x_mont, size_t n, uint64_t* host_endo_table_out);
+/* the same for the points x^(first + i) * G, i < n: the slice a rank of an N-way POINT-range split of a larger MSM keeps (rank r of N:
+ * first = r n / N; its MSM over the matching slice of the scalars is its partial sum, bench.py --shard points) */
+int bbgpu_srs_generate_range(const uint64_t* x_mont, size_t first, size_t n, uint64_t* host_endo_table_out);
 
 /* drop-in for scalar_multiplication::pippenger(scalars, points, n, bucket_width) (:457-476); scalars not modified.
  * out = {x, y, z} normalised, or infinity flag set (n == 0, all-zero scalars).

@@ -491,6 +491,35 @@ def test_srs_generate_and_msm_2_20(gpu, oracle, golden):
                     parts.append(gpu.msm_wait(tickets.pop(0)))
             parts += [gpu.msm_wait(t) for t in tickets]
             _check(gpu.g1_sum(np.stack(parts)), case)
+    # ... and the POINT-range split (bench.py --shard points, the default from round 3 on): rank r holds points and scalars
+    # [n r / N, n (r + 1) / N) as its own SRS (bbgpu_set_point_share + bbgpu_srs_generate_range), all digit windows; four in flight, so the shares
+    # after the first take the throughput choices (longer chunks, two-step row / column sums).  N = 8 and N = 3 (uneven ranges).
+    for N in (8, 3):
+        cuts = [n * r // N for r in range(N + 1)]
+        gpu.set_point_share(N)
+        slices = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            hs, ts = gpu.srs_generate(x, b - a, want_host_table=True, first=a)
+            assert np.array_equal(ts, table[2 * a:2 * b])  # the slice IS that range of the whole table
+            slices.append(hs)
+        gpu.set_point_share(1)
+        tickets, parts = [], []
+        for r, hs in enumerate(slices):
+            tickets.append(gpu.msm_device_async(hs, d_sc.data_ptr() + cuts[r] * 32, cuts[r + 1] - cuts[r]))
+            if len(tickets) == 4:
+                parts.append(gpu.msm_wait(tickets.pop(0)))
+        parts += [gpu.msm_wait(t) for t in tickets]
+        _check(gpu.g1_sum(np.stack(parts)), case)
+        # the same ranges of the WHOLE table (offset calls), two in flight
+        tickets, parts2 = [], []
+        for r in range(N):
+            tickets.append(gpu.msm_device_async(h, d_sc.data_ptr() + cuts[r] * 32, cuts[r + 1] - cuts[r], cuts[r]))
+            if len(tickets) == 2:
+                parts2.append(gpu.msm_wait(tickets.pop(0)))
+        parts2 += [gpu.msm_wait(t) for t in tickets]
+        assert np.array_equal(np.stack(parts), np.stack(parts2))
+        for hs in slices:
+            gpu.srs_release(hs)
 
 
 def test_msm_bucket_range_shares(gpu, oracle, msm_small, golden):

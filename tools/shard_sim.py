@@ -17,7 +17,7 @@ sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64); sc[:, 3] &= np.uint
 d = torch.from_numpy(sc.view(np.int64)).cuda()
 W = G.srs_num_windows(srs, n)
 base = None
-report = {"what": "one rank's share of a 2^20-point MSM on one MI355X, ms per step (median of 5 x 24 steps), no exchange step", "windows": W, "bucket_range": {}, "row_range": {}, "whole_windows": {}}
+report = {"what": "one rank's share of a 2^20-point MSM on one MI355X, ms per step (median of 5 x 24 steps), no exchange step", "windows": W, "point_range": {}, "bucket_range": {}, "row_range": {}, "whole_windows": {}}
 
 
 def timed(run):
@@ -78,6 +78,33 @@ for N in (1, 2, 4, 8):
         if depth == 2:
             report["bucket_range"]["N=%d" % N]["speedup_vs_N1"] = bbase / dt
         print("buckets N=%d, %d in flight: %.3f ms/step%s" % (N, depth, dt * 1e3, "  = %.2fx of N=1" % (bbase / dt) if bbase else ""), flush=True)
+
+# point-range shares (bench.py's default from round 3 on): a middle rank's n / N points as its own SRS (bbgpu_set_point_share + bbgpu_srs_generate_range), all windows
+pbase = None
+for N in (1, 2, 4, 8):
+    m = n // N
+    off = m * (N // 2)
+    G.set_point_share(N)
+    slice_srs = G.srs_generate(x, m, first=off) if N > 1 else srs
+    G.set_point_share(1)
+    for depth in (1, 2, 3, 4):
+        def run(k):
+            infl = []
+            for _ in range(k):
+                infl.append(G.msm_device_async(slice_srs, d.data_ptr() + off * 32, m))
+                if len(infl) == depth:
+                    G.msm_wait(infl.pop(0))
+            while infl:
+                G.msm_wait(infl.pop(0))
+        dt = timed(run)
+        if pbase is None and depth == 2:
+            pbase = dt
+        report["point_range"].setdefault("N=%d" % N, {})["ms_per_step_%d_in_flight" % depth] = dt * 1e3
+        if pbase:
+            report["point_range"]["N=%d" % N]["speedup_vs_N1_%d_in_flight" % depth] = pbase / dt
+        print("points N=%d, %d in flight: %.3f ms/step%s" % (N, depth, dt * 1e3, "  = %.2fx of N=1" % (pbase / dt) if pbase else ""), flush=True)
+    if N > 1:
+        G.srs_release(slice_srs)
 
 # host-side cost of one step at the smallest share: time inside the two calls
 rows8 = W * n // 8

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """workload for a timeline under rocprofv3 --kernel-trace: a middle 1/N share of a 2^20 MSM, `depth` in flight, 40 steps.
-usage: share_run.py rows|buckets N depth"""
+usage: share_run.py rows|buckets|points N depth"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,7 +17,9 @@ W = G.srs_num_windows(srs, n)
 rows = W * n // N
 infl = []
 for _ in range(40):
-    infl.append(G.msm_device_rows_async(srs, d.data_ptr(), n, rows * (N // 2), rows * (N // 2 + 1)) if kind == "rows" else G.msm_device_buckets_async(srs, d.data_ptr(), n, N // 2, N))
+    if kind == "rows": infl.append(G.msm_device_rows_async(srs, d.data_ptr(), n, rows * (N // 2), rows * (N // 2 + 1)))
+    elif kind == "points": infl.append(G.msm_device_async(srs, d.data_ptr() + (n // N) * (N // 2) * 32, n // N, (n // N) * (N // 2)))
+    else: infl.append(G.msm_device_buckets_async(srs, d.data_ptr(), n, N // 2, N))
     if len(infl) == depth: G.msm_wait(infl.pop(0))
 while infl: G.msm_wait(infl.pop(0))
 torch.cuda.synchronize()
