@@ -357,6 +357,13 @@ __device__ __forceinline__ Radix4Out radix4_lazy(const FrS& x0, const FrS& x1, c
     const auto a2 = add(x2, t3);                                                // 5 U
     const auto a3 = sub(x2, t3);                                                // 6 U: the multiplier's limit
     const auto u2 = exact_limbs(mul(w2a, a2)), u3 = exact_limbs(mul(w2b, a3));
+#ifdef BBGPU_NTT_JUNK // issue-model experiment: k extra cheap VALU instructions per multiplication of a stage pair, results unused
+    {
+        uint32_t j0 = x0.d[0], j1 = x1.d[0];
+#pragma unroll
+        for (int q = 0; q < 2 * BBGPU_NTT_JUNK; q++) asm volatile("v_and_b32 %0, 0x1fffffff, %1\n\tv_add_u32 %1, %0, %1" : "+v"(j0), "+v"(j1));
+    }
+#endif
     Radix4Out o;
     o.y0 = assume_bound<3, NTT_VMAX>(add(a0, u2));
     o.y2 = assume_bound<4, NTT_VMAX>(sub(a0, u2));

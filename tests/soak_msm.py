@@ -46,7 +46,7 @@ while time.time() < t_end:
         print("MISMATCH n=%d kind=%d" % (n, kind), flush=True)
 print("oracle comparisons: %d cases, %d mismatches" % (cases, bad), flush=True)
 
-# shares (round 3): N bucket-range shares and N row-range shares of random sizes / scalar mixtures must add up to the one-call result
+# shares (round 3): N bucket-range shares, N row-range shares and N point-range shares of random sizes / scalar mixtures must add up to the one-call result
 t2 = time.time() + budget / 4
 share_cases = share_bad = 0
 while time.time() < t2:
@@ -71,12 +71,22 @@ while time.time() < t2:
     cuts = [W * n * r // Nn for r in range(Nn + 1)]
     parts = [G.msm_wait(G.msm_device_rows_async(h, d.data_ptr(), n, a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
     okr = np.array_equal(G.g1_sum(np.stack(parts)), full)
+    # point-range shares (bench.py --shard points): ranges of the whole table, up to four in flight (the throughput choices of msm_issue_batch)
+    pc = [n * r // Nn for r in range(Nn + 1)]
+    tickets, parts = [], []
+    for a, b in zip(pc[:-1], pc[1:]):
+        if b > a:
+            tickets.append(G.msm_device_async(h, d.data_ptr() + a * 32, b - a, a))
+        if len(tickets) == 4:
+            parts.append(G.msm_wait(tickets.pop(0)))
+    parts += [G.msm_wait(t) for t in tickets]
+    okp = np.array_equal(G.g1_sum(np.stack(parts)), full)
     share_cases += 1
-    if not (okb and okr):
+    if not (okb and okr and okp):
         share_bad += 1
-        print("SHARE MISMATCH n=%d kind=%d N=%d buckets_ok=%s rows_ok=%s" % (n, kind, Nn, okb, okr), flush=True)
+        print("SHARE MISMATCH n=%d kind=%d N=%d buckets_ok=%s rows_ok=%s points_ok=%s" % (n, kind, Nn, okb, okr, okp), flush=True)
     G.srs_release(h)
-print("share splits: %d cases (bucket and row shares, 1..8 ranks), %d mismatches" % (share_cases, share_bad), flush=True)
+print("share splits: %d cases (bucket, row and point-range shares, 1..8 ranks), %d mismatches" % (share_cases, share_bad), flush=True)
 bad += share_bad
 
 # pipelined: 4 different scalar vectors, two and three in flight, against their one-at-a-time results, at 2^15 and 2^20
