@@ -325,6 +325,9 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
     // Measured: single 2^20 MSM 1.611 -> 1.546 ms, two in flight 1.345 -> 1.287 ms/step (-4.3 %); prover 2^19 gates 11.89 -> 11.51 ms,
     // 2^20 gates 22.1-22.8 -> 22.0 ms; 2^18 gates unchanged (6.8 ms), so smaller tables keep c = 15
     if (n_for_c >= ((size_t)1 << 19)) c = 17;
+    // ... but a slice of fewer than 2^18 points pays the row / column sums over 2^16 buckets for ~30 entries per bucket: 16-bit windows (2^15 buckets, one window
+    // more) measured 0.179 against 0.182 ms per step at 2^17 points, four in flight, three alternating runs (15-bit windows: 0.189)
+    if (g_ctx.point_world > 1 && c == 17 && n < ((size_t)1 << 18)) c = 16;
     if (const char* ev = getenv("BBGPU_TABLE_C")) c = std::min(17, std::max(4, atoi(ev))); // tuning knob: window size of the tables
     const int W = msm_num_windows(c);
     const bool want_tab = g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24);

@@ -617,6 +617,10 @@ def test_msm_skewed_scalars_full_size(gpu, oracle, golden):
         d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
         _check(gpu.msm_device(h, d.data_ptr(), n), case)
         _check(gpu.msm_device(h, d.data_ptr(), 1 << 14), case["first_16384"])
+        # three in flight: the MSMs behind the first take the throughput choices (two-step row / column sums, longer chunks) on the same heavy buckets
+        tickets = [gpu.msm_device_async(h, d.data_ptr(), n) for _ in range(3)]
+        for t in tickets:
+            _check(gpu.msm_wait(t), case)
     gpu.srs_release(h)
 
 

@@ -42,6 +42,9 @@ python tools/small_sizes.py > $OUT/small_sizes.txt 2>&1
 python tools/exchange_cost.py > $OUT/exchange_cost.txt 2>&1
 python tools/host_finish_cost.py > $OUT/host_finish_cost.txt 2>&1
 python tools/share_ab.py 8 4 2 > $OUT/share_ab.txt 2>&1
+python tools/point_share_ab.py 8 4 2 > $OUT/point_share_ab.txt 2>&1
+python tools/issue_cost.py > $OUT/issue_cost.txt 2>&1
+( cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq8 -- python3 $ROOT/tools/share_run.py points 8 2 > $OUT/sq8.log 2>&1 ) && python tools/pmc_sq_summary.py $OUT/sq8 $OUT/${TAG}_pmc_sq_share8_points.json > /dev/null; rm -rf $OUT/sq8
 python tools/skewed_stages.py > $OUT/skewed_stages.txt 2>&1
 python tools/boundary_ab.py > $OUT/boundary_ab.txt 2>&1
 BBGPU_HOST_MSM_SPLIT=1 python tools/boundary_ab.py >> $OUT/boundary_ab.txt 2>&1
