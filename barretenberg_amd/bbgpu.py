@@ -95,7 +95,8 @@ class BbGpu:
         L.bbgpu_ntt_device_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, u64p, C.c_void_p]
         L.bbgpu_srs_register.argtypes = [u64p, C.c_size_t]
         L.bbgpu_srs_generate.argtypes = [u64p, C.c_size_t, u64p]
-        L.bbgpu_srs_generate_range.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
+        if hasattr(L, "bbgpu_srs_generate_range"):  # absent from older A/B builds loaded through BBGPU_LIB
+            L.bbgpu_srs_generate_range.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
         L.bbgpu_msm_g1.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1_plain.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1_batch.argtypes = [C.POINTER(MsmJob), C.c_size_t]
@@ -208,8 +209,9 @@ class BbGpu:
     def srs_generate(self, x_mont, n, want_host_table=False, first=0):
         """resident points x^(first + i) G, i < n (first > 0: the slice of a rank of a point-range split)"""
         table = np.zeros((2 * n, 8), dtype=np.uint64) if want_host_table else None
-        h = self._chk(self.lib.bbgpu_srs_generate_range(_ptr(np.ascontiguousarray(x_mont, dtype=np.uint64)), first, n,
-                                                        _ptr(table) if want_host_table else None))
+        xa = np.ascontiguousarray(x_mont, dtype=np.uint64)
+        xp, tp = _ptr(xa), (_ptr(table) if want_host_table else None)
+        h = self._chk(self.lib.bbgpu_srs_generate_range(xp, first, n, tp) if first else self.lib.bbgpu_srs_generate(xp, n, tp))
         return (h, table) if want_host_table else h
 
     def read_transcript(self, path, degree):
