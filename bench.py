@@ -339,6 +339,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
     ap.add_argument("--probe", action="store_true", help="no GPU work: form the process group of the N ranks, report who is there, exit (launch check)")
+    ap.add_argument("--no-window-split-leg", action="store_true", help="N > 1 with the default split: skip the extra timed leg that runs the same MSM split by window rows")
     ap.add_argument("--shard", default="points", choices=("points", "buckets", "rows", "windows"),
                     help="N > 1: how one MSM is split over the ranks (points: rank r holds points and scalars [n r / N, n (r + 1) / N) with all their digit windows -- "
                          "the reference's own per-thread slicing, and the one split where the digit kernel's work divides by N too; "
@@ -512,6 +513,37 @@ def main():
         full = G.msm_device(srs_full, d_scalars.data_ptr(), n)
         G.srs_release(srs_full)
         sharded_ok = bool(np.array_equal(full, res))
+
+    # ---- N > 1, default (point-range) split: the north star's WINDOW split of the same MSM next to it -- every rank 1/N of the window-major (window, point)
+    # rows of its own window tables (whole windows when N divides W), same pipeline, same exchange, timed the same way; reported as `window_split`
+    window_split = None
+    if by_points and not args.no_window_split_leg:
+        G.set_table_share(rank, world)
+        srs_rows = G.srs_generate(x_secret, n)
+        G.set_table_share(0, 1)
+        Wr = G.srs_num_windows(srs_rows, n)
+        rr = (Wr * n * rank // world, Wr * n * (rank + 1) // world)
+
+        def issue_rows():
+            return G.msm_device_rows_async(srs_rows, d_scalars.data_ptr(), n, rr[0], rr[1]) if rr[1] > rr[0] else None
+
+        def run_rows(k):
+            out = pipelined_steps(k, issue_rows, collect, exchange, depth=depth)
+            return out[-1] if out else None
+
+        run_rows(20 + args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        res_rows = run_rows(args.steps)
+        barrier()
+        dt_rows = time.perf_counter() - t0
+        tt = torch.tensor([dt_rows], dtype=torch.float64, device=xdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_rows = float(tt.item())
+        window_split = {"what": "the same MSM split by table row = window-major (window, point) pairs, W n / N rows per rank (bench.py --shard rows), same steps / warm-up / exchange",
+                        "ms_per_step": dt_rows / args.steps * 1e3, "value": n / (dt_rows / args.steps), "result_equals_point_split": bool(np.array_equal(res_rows, res))}
+        G.srs_release(srs_rows)
+        stage_log.clear()
 
     # ---- the same stages with nothing else on the GPU (one MSM at a time), for comparison ---------------------------
     G.set_timing(True)
@@ -738,6 +770,8 @@ def main():
             line["boundary"] = boundary
         if sharded_ok is not None:
             line["sharded_result_equals_single_gpu"] = sharded_ok
+        if window_split is not None:
+            line["window_split"] = window_split
         if plonk is not None:
             line["plonk"] = plonk
         if cpu_leg:
