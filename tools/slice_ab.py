@@ -14,7 +14,9 @@ rng = np.random.default_rng(7)
 x = rng.integers(0, 1 << 64, size=4, dtype=np.uint64); x[3] &= np.uint64(0x1FFFFFFFFFFFFFFF)
 sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64); sc[:, 3] &= np.uint64(0x1FFFFFFFFFFFFFFF)
 d = torch.from_numpy(sc.view(np.int64)).cuda()
+G.set_point_share(N)  # as bench.py --shard points: the window size of the whole MSM (BBGPU_TABLE_C still overrides)
 srs = G.srs_generate(x, m, first=off)
+G.set_point_share(1)
 W = G.srs_num_windows(srs, m)
 def timed(issue, depth):
     def run(k):
