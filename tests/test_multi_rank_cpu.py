@@ -62,6 +62,51 @@ def test_window_sharded_partial_sums_fold_over_gloo():
     assert ret.get(timeout=10) == 1
 
 
+def _point_range_worker(rank, world, port, n, ret):
+    """the split bench.py uses by default for N > 1: rank r holds points and scalars [n r / N, n (r + 1) / N) with all their digit windows (the reference's
+    own slicing, scalar_multiplication.cpp:703-738); its partial sum here is the oracle's MSM over that range, the fold is the library's bbgpu_g1_sum"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from barretenberg_amd import BbGpu
+    from oracle.pyoracle import Oracle, aligned_copy
+    O = Oracle()
+    lib = BbGpu(init=False)
+    x = O.random_scalars(0x5EED0F5EC2E7C0DE, 1)[0]
+    table = O.point_table(O.make_srs(x, n))
+    scalars = O.random_scalars(0x9E3779B97F4A7C15, n)
+    a, b = n * rank // world, n * (rank + 1) // world  # uneven when world does not divide n
+    part = np.zeros(12, dtype=np.uint64)
+    part[7] = np.uint64(1 << 63)  # an empty range contributes the point at infinity
+    if b > a:
+        part = O.msm_affine(aligned_copy(scalars[a:b]), aligned_copy(table[2 * a:2 * b]), b - a)
+    mine = torch.from_numpy(part.view(np.int64).copy())
+    bufs = [torch.empty(12, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    total = lib.g1_sum(torch.stack(bufs).numpy().view(np.uint64))
+    want = O.msm_affine(scalars, table, n)
+    ok = bool(np.array_equal(total[:8], want[:8]))
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret.put(int(t.item()))
+    dist.destroy_process_group()
+
+
+def test_point_range_partial_sums_fold_over_gloo():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_point_range_worker, args=(r, 2, port, 37, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert ret.get(timeout=10) == 1
+
+
 def _pipeline_worker(rank, world, port, ret):
     """the step loop bench.py runs for N > 1 (barretenberg_amd/sharding.py) with the GPU work replaced by oracle points: step s of rank r
     contributes (s + 1) * (r + 2) * G; the folded result of step s must be (s + 1) * (2 + 3) * G, in step order, on every rank"""
