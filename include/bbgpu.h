@@ -168,7 +168,8 @@ int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars
 /* Asynchronous form: enqueue (returns a ticket >= 0, or a negative error) and collect later.  Up to eight MSMs may be in
  * flight; the bucket-reduction tail and host finish of one then overlap the sort/accumulate of the next, and
  * small latency-bound MSMs (a prover round's three commitments) run side by side.  With hip_stream == NULL each ticket runs
- * on its own internal stream. */
+ * on its own internal stream.  An MSM enqueued while another is in flight is laid out for throughput instead of latency (longer
+ * accumulation chunks, row / column sums in two steps: DESIGN.md 5, 6 v); the result is the same point either way. */
 int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                               int window_end, void* hip_stream);
 /* The same with a share that may start and end INSIDE a digit window: rows [row_begin, row_end) of the W x n (window, point) pairs counted
