@@ -23,7 +23,10 @@ pool = O.random_scalars(12, N)
 one = O.const(FR, "one"); minus_one = O.neg(FR, one); zero = np.zeros(4, dtype=np.uint64)
 t_end = time.time() + budget
 cases = bad = 0
+t_say = time.time() + 60  # a progress line a minute: a GPU command silent for 7 minutes is taken to be hung and killed
 while time.time() < t_end:
+    if time.time() > t_say:
+        print("... %d oracle comparisons so far, %d mismatches" % (cases, bad), flush=True); t_say = time.time() + 60
     n = int(rng.integers(25, 20000))
     if rng.integers(0, 3) == 0:
         n &= ~7
@@ -50,6 +53,8 @@ print("oracle comparisons: %d cases, %d mismatches" % (cases, bad), flush=True)
 t2 = time.time() + budget / 4
 share_cases = share_bad = 0
 while time.time() < t2:
+    if time.time() > t_say:
+        print("... %d share splits so far, %d mismatches" % (share_cases, share_bad), flush=True); t_say = time.time() + 60
     n = int(rng.integers(1024, 20000))
     if rng.integers(0, 2) == 0:
         n &= ~7
@@ -102,6 +107,8 @@ for lg in (15, 20):
     rounds = mism = 0
     t1 = time.time() + budget / 4
     while time.time() < t1:
+        if time.time() > t_say:
+            print("... pipelined 2^%d: %d rounds so far, %d differing" % (lg, rounds, mism), flush=True); t_say = time.time() + 60
         for depth in (2, 3):
             infl, out = [], []
             for k in range(12):

@@ -21,7 +21,10 @@ pool = O.random_scalars(4, 1 << 16)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 bad = cases = 0
 t_end = time.time() + budget * 0.6
+t_say = time.time() + 60  # a progress line a minute: a GPU command silent for 7 minutes is taken to be hung and killed
 while time.time() < t_end:
+    if time.time() > t_say:
+        print("... %d transforms so far, %d mismatches" % (cases, bad), flush=True); t_say = time.time() + 60
     lg, lg2 = int(rng.integers(1, 17)), int(rng.integers(8, 17))
     n, n2 = 1 << lg, 1 << lg2
     kind, kind2 = kinds[int(rng.integers(0, len(kinds)))], kinds[int(rng.integers(0, len(kinds)))]
@@ -50,6 +53,8 @@ first = P.construct_proof()
 t_end = time.time() + budget * 0.4
 proofs = diff = 0
 while time.time() < t_end:
+    if time.time() > t_say:
+        print("... %d proofs so far, %d differing" % (proofs, diff), flush=True); t_say = time.time() + 60
     p = P.construct_proof()
     proofs += 1
     if not np.array_equal(p, first):
