@@ -401,6 +401,10 @@ int pick_slot()
 }
 int issue_on_entry(MsmSlot& S, const SrsEntry& e, size_t off, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st)
 {
+    // the synchronous entry points use slots 0 / 1 directly (the point ranges of a host-pointer MSM, the jobs of a host-pointer batch): the same hint as pick_slot()
+    bool others = false;
+    for (int k = 0; k < Context::NSLOT; k++) others = others || (&g_ctx.slot[k] != &S && g_ctx.slot[k].pending);
+    S.throughput = others;
     if (!windows_resident(e, wb, we)) return BBGPU_ERR_STATE;
     return msm_issue(S, e.d_srs + off * 16, e.d_tab ? e.d_tab + off * 16 : nullptr, e.n, e.tab_c, d_scalars, n, wb, we, st, g_ctx.timing);
 }
