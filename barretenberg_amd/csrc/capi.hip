@@ -526,7 +526,8 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
     // upload is the part nothing hides, and the second range's upload (0.6 ms x its share) still fits under the first one's kernels.
     const size_t ranges = split_env ? split_env : (n >= ((size_t)1 << 19) ? 2 : 1);
     if (ranges > 1 && !g_ctx.slot[1].pending) {
-        const size_t base = ranges == 2 ? ((n * 3 / 8) & ~(size_t)7) : n / ranges;
+        static const size_t first_pct = [] { const char* v = getenv("BBGPU_HOST_MSM_FIRST_PCT"); return v ? (size_t)std::min(50, std::max(5, atoi(v))) : (size_t)0; }(); // tuning knob; measured 25 / 30 / 34 / 37 / 42 %: 1.84 / 1.80 / 1.83 / 1.775 / 1.79 ms
+        const size_t base = ranges == 2 ? (((first_pct ? n * first_pct / 100 : n * 3 / 8)) & ~(size_t)7) : n / ranges;
         uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
         size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
         res = host::g1_infinity();
