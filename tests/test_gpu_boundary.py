@@ -180,6 +180,42 @@ def test_rank_share_of_the_window_tables(gpu, oracle, tables):
         assert np.array_equal(gpu.g1_sum(np.stack(parts))[:8], want[:8]), world
 
 
+def test_point_range_slices_against_the_oracle(gpu, oracle, tables):
+    """the other multi-GPU split (bbgpu_set_point_share, bench.py --shard points): rank r registers points [n r / N, n (r + 1) / N) of the table as its own SRS and
+    runs the ordinary MSM over the matching scalars; the N results (uneven ranges, up to four in flight) fold to the oracle's point.  The call only moves the
+    window size of the slice's tables: slices of 2^17 / 2^18 points of a 2^20-point MSM take 16 / 17 bits (16 / 15 windows), alone they take 15 bits (17 windows)"""
+    import torch
+    (A, B, C), small, sc = tables
+    n = 2048
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    want = oracle.msm_affine(sc, A, n)
+    for world in (2, 3, 8):
+        cuts = [n * r // world for r in range(world + 1)]
+        gpu.set_point_share(world)
+        hs = [gpu.srs_register(aligned_copy(A[2 * a:2 * b])) for a, b in zip(cuts[:-1], cuts[1:])]
+        gpu.set_point_share(1)
+        tickets, parts = [], []
+        for r, h in enumerate(hs):
+            tickets.append(gpu.msm_device_async(h, d.data_ptr() + cuts[r] * 32, cuts[r + 1] - cuts[r]))
+            if len(tickets) == 4:
+                parts.append(gpu.msm_wait(tickets.pop(0)))
+        parts += [gpu.msm_wait(t) for t in tickets]
+        assert np.array_equal(gpu.g1_sum(np.stack(parts))[:8], want[:8]), world
+        for h in hs:
+            gpu.srs_release(h)
+    probe = gpu.srs_register(aligned_copy(A))
+    with_tables = gpu.srs_has_window_tables(probe)
+    gpu.srs_release(probe)
+    if with_tables:  # the suite's pass without tables has no window size to look at
+        x = np.array([3, 0, 0, 0], dtype=np.uint64)
+        for world, m, windows in ((8, 1 << 17, 16), (4, 1 << 18, 15), (1, 1 << 17, 17)):
+            gpu.set_point_share(world)
+            h = gpu.srs_generate(x, m, first=5)
+            gpu.set_point_share(1)
+            assert gpu.srs_num_windows(h, m) == windows, (world, m)
+            gpu.srs_release(h)
+
+
 def test_partial_sum_exchange_over_rccl_world_size_1(gpu, oracle, tables):
     """the multi-GPU MSM's one exchange step over backend nccl (= RCCL) with the ranks this box has: init, all_gather of the
     96-byte partial sums on the GPU, identical fold -- the same objects bench.py uses for N > 1 (barretenberg_amd/sharding.py)"""
