@@ -323,7 +323,8 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
     if (n_for_c >= ((size_t)1 << 16) && c < 15) c = 15;
     // 17-bit windows (15 instead of 16 of them, signed digits up to +-2^16 kept as uint16 magnitude + sign bit, 2^16 buckets): one n-th fewer mixed additions.
     // Measured: single 2^20 MSM 1.611 -> 1.546 ms, two in flight 1.345 -> 1.287 ms/step (-4.3 %); prover 2^19 gates 11.89 -> 11.51 ms,
-    // 2^20 gates 22.1-22.8 -> 22.0 ms; 2^18 gates unchanged (6.8 ms), so smaller tables keep c = 15
+    // 2^20 gates 22.1-22.8 -> 22.0 ms; 2^18 gates unchanged (6.8 ms), so smaller tables keep c = 15 (measured again at the end of round 3, tools/plonk_bench.py:
+    // 2^17 gates 3.51 / 3.40-3.50 / 3.49-3.52 ms at c = 15 / 16 / 17, 2^18 gates 5.74-5.80 / 5.58-5.87 / 5.58-5.63: within 3 %, and the reference fixtures sit around the 2^19 switch)
     if (n_for_c >= ((size_t)1 << 19)) c = 17;
     // ... but a slice of fewer than 2^18 points pays the row / column sums over 2^16 buckets for ~30 entries per bucket: 16-bit windows (2^15 buckets, one window
     // more) measured 0.179 against 0.182 ms per step at 2^17 points, four in flight, three alternating runs (15-bit windows: 0.189)
