@@ -50,6 +50,8 @@ C_ABI_SYMBOLS = [
     "bbgpu_generate_point_table",
     "bbgpu_plonk_prover_create", "bbgpu_plonk_prover_set_witness", "bbgpu_plonk_construct_proof", "bbgpu_plonk_preprocess", "bbgpu_plonk_last_challenges",
     "bbgpu_plonk_last_timing", "bbgpu_plonk_prover_destroy", "bbgpu_plonk_challenges_from_proof",
+    "bbgpu_host_msm_g1", "bbgpu_host_ntt", "bbgpu_host_fr_evaluate", "bbgpu_host_kate_opening", "bbgpu_host_lagrange_l1_fft",
+    "bbgpu_host_divide_by_pseudo_vanishing",
 ]
 
 
@@ -330,6 +332,44 @@ class BbGpu:
         out = np.zeros(12, dtype=np.uint64)
         self._chk(self.lib.bbgpu_g1_sum(_ptr(points12), points12.shape[0], _ptr(out)))
         return out
+
+    # ---- host fallbacks of the drop-in boundary (what the C++ shim computes with after a GPU call has failed; no GPU needed) -----
+    def host_msm(self, scalars, points, n=None, plain=False):
+        n = scalars.shape[0] if n is None else n
+        out = np.zeros(12, dtype=np.uint64)
+        self.lib.bbgpu_host_msm_g1.argtypes = [u64p, u64p, C.c_size_t, C.c_int, u64p]
+        self._chk(self.lib.bbgpu_host_msm_g1(_ptr(scalars), _ptr(points), n, int(plain), _ptr(out)))
+        return out
+
+    def host_ntt(self, coeffs, kind, constant=None):
+        kind = NTT_KINDS[kind] if isinstance(kind, str) else kind
+        cp = _ptr(np.ascontiguousarray(constant, dtype=np.uint64)) if constant is not None else None
+        self.lib.bbgpu_host_ntt.argtypes = [u64p, C.c_size_t, C.c_int, u64p]
+        self._chk(self.lib.bbgpu_host_ntt(_ptr(coeffs), coeffs.shape[0], kind, cp))
+        return coeffs
+
+    def host_evaluate(self, coeffs, z):
+        out = np.zeros(4, dtype=np.uint64)
+        self.lib.bbgpu_host_fr_evaluate.argtypes = [u64p, C.c_size_t, u64p, u64p]
+        self._chk(self.lib.bbgpu_host_fr_evaluate(_ptr(coeffs), coeffs.shape[0], _ptr(np.ascontiguousarray(z, dtype=np.uint64)), _ptr(out)))
+        return out
+
+    def host_kate_opening(self, src, z):
+        dest, f = np.zeros_like(src), np.zeros(4, dtype=np.uint64)
+        self.lib.bbgpu_host_kate_opening.argtypes = [u64p, u64p, C.c_size_t, u64p, u64p]
+        self._chk(self.lib.bbgpu_host_kate_opening(_ptr(src), _ptr(dest), src.shape[0], _ptr(np.ascontiguousarray(z, dtype=np.uint64)), _ptr(f)))
+        return dest, f
+
+    def host_lagrange_l1_fft(self, n_src, n_target):
+        out = np.zeros((n_target, 4), dtype=np.uint64)
+        self.lib.bbgpu_host_lagrange_l1_fft.argtypes = [u64p, C.c_size_t, C.c_size_t]
+        self._chk(self.lib.bbgpu_host_lagrange_l1_fft(_ptr(out), n_src, n_target))
+        return out
+
+    def host_divide_by_pseudo_vanishing(self, coeffs, n_src, n_target):
+        self.lib.bbgpu_host_divide_by_pseudo_vanishing.argtypes = [u64p, C.c_size_t, C.c_size_t]
+        self._chk(self.lib.bbgpu_host_divide_by_pseudo_vanishing(_ptr(coeffs), n_src, n_target))
+        return coeffs
 
     # ---- device self-test (known-answer entry points of the field / group layer) ---------------------------------------
     SELFTEST_FIELD_OPS = {"mul": 0, "sqr": 1, "add": 2, "sub": 3, "neg": 4, "mul_add": 5, "mul_sub": 6, "lazy_limbs": 7, "lazy_weak": 8,

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/bbgpu.h"
 
 namespace bbgpu {
@@ -68,6 +70,7 @@ int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_
 void host_stage_release();
 
 // plonk.hip
-void plonk_release_all();
+std::mutex& plonk_mutex();        // taken BEFORE capi.hip's mutex wherever both are held
+void plonk_release_all_locked();  // caller holds plonk_mutex()
 
 } // namespace bbgpu

@@ -16,6 +16,7 @@
 #include "host_g1.hpp"
 #include "host_g2.hpp"
 #include "host_small.hpp"
+#include "host_fallback.hpp"
 #include "host_copy_pool.hpp"
 #include "poly.h"
 
@@ -134,9 +135,11 @@ int ensure_init()
     // MSM with 8 queues, a 1/8 share four in flight 0.232 -> 0.205).  16: the eight slot streams, the library's own and the caller's.  Only effective when this is the process's first HIP call; a host
     // program that initialises HIP earlier sets the variable itself (bench.py and the Python binding do).
     (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
-        set_error("no HIP device available: libbbgpu has no CPU fallback");
+    // asked once per process: without a device every call would repeat the runtime's probe of the machine (~10 ms each; the shim's host
+    // answers would be paced by it)
+    static const int cnt = [] { int c = 0; return hipGetDeviceCount(&c) == hipSuccess ? c : 0; }();
+    if (cnt == 0) {
+        set_error("no HIP device available: the GPU entry points of libbbgpu have no CPU fallback");
         return BBGPU_ERR_HIP;
     }
     CHK(hipSetDevice(g_ctx.device));
@@ -193,8 +196,12 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
 // stall is small against the work (profiles/r03_pcie.txt).
 static host::CopyPool g_copy_pool; // CPU copies into / out of the pinned staging buffers (host_copy_pool.hpp)
 
+// Both directions take the library mutex themselves (recursive: the capi entry points already hold it): the resident prover's uploads
+// (plonk.hip, which holds only its own mutex) would otherwise race with a transform or an MSM of another thread on the staging buffers,
+// their events and the single-producer copy pool.  Lock order everywhere: the prover's mutex first, then this one.
 int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     read_host_env();
     if (bytes == 0) return BBGPU_OK;
     if (bytes > g_ctx.host_stage_max) {
@@ -220,6 +227,7 @@ int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
 // device -> caller's buffer, complete on return (everything enqueued on `st` before it has run as well)
 int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     read_host_env();
     if (bytes > g_ctx.host_stage_max) {
         CHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
@@ -259,6 +267,7 @@ int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_
 }
 void host_stage_release()
 {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     g_copy_pool.shutdown();
     for (int k = 0; k < 2; k++) {
         if (g_ctx.h_stage[k]) (void)hipHostFree(g_ctx.h_stage[k]);
@@ -603,11 +612,23 @@ int bbgpu_init(int device)
 
 void bbgpu_shutdown(void)
 {
+    // lock order: the prover's mutex, then the library's (the prover calls the entry points above while it holds its own)
+    std::lock_guard<std::mutex> lkp(plonk_mutex());
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g_ctx.ready) return;
-    plonk_release_all();
-    host_stage_release();
+    plonk_release_all_locked();
+    // nothing may still be reading the pinned staging buffers or a slot's workspace when they are freed: collect what is in flight
+    // (an MSM a caller never waited for, a copy queued before an error return) and drain every stream first
+    for (auto& sl : g_ctx.slot)
+        if (sl.pending) {
+            host::Xyzz dump[4];
+            (void)msm_finish_batch(sl, dump, nullptr);
+        }
     (void)hipStreamSynchronize(g_ctx.stream);
+    for (auto& sl : g_ctx.slot)
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    (void)hipDeviceSynchronize();
+    host_stage_release();
     g_ctx.poly_scratch.release();
     if (g_ctx.d_poly_tmp) (void)hipFree(g_ctx.d_poly_tmp);
     g_ctx.d_poly_tmp = nullptr;
@@ -713,7 +734,8 @@ int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
     if ((rc = host_to_device(g_ctx.d_stage, coeffs, n * 32, g_ctx.stream)) != BBGPU_OK) return rc;
     rc = bbgpu_ntt_device(g_ctx.d_stage, n, kind, constant, g_ctx.stream);
     if (rc) return rc;
-    return device_to_host_sync(coeffs, g_ctx.d_stage, n * 32, g_ctx.stream);
+    // up to here `coeffs` is untouched; a failure while the result is copied back may leave it half overwritten
+    return device_to_host_sync(coeffs, g_ctx.d_stage, n * 32, g_ctx.stream) == BBGPU_OK ? BBGPU_OK : BBGPU_ERR_LOST;
 }
 
 /* ---- resident polynomial helpers ---- */
@@ -881,7 +903,7 @@ int bbgpu_divide_by_pseudo_vanishing(uint64_t* coeffs, size_t n_src, size_t n_ta
     if (!coeffs) return BBGPU_ERR_ARG;
     if ((rc = stage_in(coeffs, n_target)) != BBGPU_OK) return rc;
     if ((rc = bbgpu_divide_by_pseudo_vanishing_device(g_ctx.d_stage, n_src, n_target, g_ctx.stream)) != BBGPU_OK) return rc;
-    return stage_out(coeffs, g_ctx.d_stage, n_target);
+    return stage_out(coeffs, g_ctx.d_stage, n_target) == BBGPU_OK ? BBGPU_OK : BBGPU_ERR_LOST; // in place, as in bbgpu_ntt
 }
 
 // polynomial_arithmetic::get_lagrange_evaluations (polynomial_arithmetic.cpp:594-626): {Z_H*(z), L_1(z), L_{n-1}(z)}; host arithmetic
@@ -921,6 +943,63 @@ int bbgpu_generate_point_table(const uint64_t* points, uint64_t* table, size_t n
         memcpy(e, x.d, 32);
         memcpy(e + 4, y.d, 32);
     }
+    return BBGPU_OK;
+}
+
+/* ---- host fallbacks: what shim/bb_shim.cpp computes with after a GPU entry has FAILED (host_fallback.hpp).  No HIP call, no lock,
+ * no shared state: re-entrant.  Never reached from the GPU entries above. ---- */
+int bbgpu_host_msm_g1(const uint64_t* scalars, const uint64_t* points, size_t n, int plain_table, uint64_t out[12])
+{
+    if (!out || (n && (!scalars || !points))) {
+        set_error("null scalars / points / out");
+        return BBGPU_ERR_ARG;
+    }
+    host::g1_to_normalised(host::msm_pippenger(scalars, points, n, plain_table ? 8 : 16), out);
+    return BBGPU_OK;
+}
+int bbgpu_host_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
+{
+    const int lg = log2_exact(n);
+    if (lg < 1 || lg > 28) {
+        set_error("NTT size %zu is not a power of two in [2, 2^28]", n);
+        return BBGPU_ERR_SIZE;
+    }
+    const bool has_const = (kind == BBGPU_FFT_WITH_CONSTANT || kind == BBGPU_IFFT_WITH_CONSTANT || kind == BBGPU_COSET_FFT_WITH_CONSTANT);
+    if (!coeffs || kind < 0 || kind > BBGPU_COSET_FFT_WITH_CONSTANT || (has_const && !constant)) {
+        set_error("bad NTT kind / null buffer");
+        return BBGPU_ERR_ARG;
+    }
+    host::ntt_radix2(coeffs, lg, kind, constant);
+    return BBGPU_OK;
+}
+int bbgpu_host_fr_evaluate(const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4])
+{
+    if ((!coeffs && n) || !z || !out) return BBGPU_ERR_ARG;
+    const host::Fr r = host::poly_evaluate(coeffs, n, load_fr(z));
+    memcpy(out, r.d, 32);
+    return BBGPU_OK;
+}
+int bbgpu_host_kate_opening(const uint64_t* src, uint64_t* dest, size_t n, const uint64_t z[4], uint64_t f_of_z[4])
+{
+    if (((!src || !dest) && n) || !z) return BBGPU_ERR_ARG;
+    const host::Fr f = host::kate_opening(src, dest, n, load_fr(z));
+    if (f_of_z) memcpy(f_of_z, f.d, 32);
+    return BBGPU_OK;
+}
+int bbgpu_host_lagrange_l1_fft(uint64_t* l_1, size_t n_src, size_t n_target)
+{
+    const int ls = log2_exact(n_src), lt = log2_exact(n_target);
+    if (!l_1) return BBGPU_ERR_ARG;
+    if (ls < 1 || lt < ls || lt > 28) return BBGPU_ERR_SIZE;
+    host::lagrange_l1_fft(l_1, ls, lt);
+    return BBGPU_OK;
+}
+int bbgpu_host_divide_by_pseudo_vanishing(uint64_t* coeffs, size_t n_src, size_t n_target)
+{
+    const int ls = log2_exact(n_src), lt = log2_exact(n_target);
+    if (!coeffs) return BBGPU_ERR_ARG;
+    if (ls < 1 || lt < ls || lt > 28) return BBGPU_ERR_SIZE;
+    host::divide_by_pseudo_vanishing(coeffs, ls, lt);
     return BBGPU_OK;
 }
 

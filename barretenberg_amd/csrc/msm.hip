@@ -921,6 +921,9 @@ constexpr int RAW_WORDS = 4 * NL; // 36 words per partial: lazy limbs, no canoni
 // workgroups that share a bucket (K4h), heavy[HEAVY_IDS ..] = bucket ids; HEAVY_WGS raw partial sums follow the id list (MsmCarve).
 constexpr uint32_t HEAVY_WGS = 256;           // workgroups of K4h
 constexpr uint32_t HEAVY_IDS = 1 + HEAVY_WGS; // first bucket id
+// block 0 of the accumulation zeroes the HEAVY_IDS header words with one lane each (+ one), and the last arriver of K4h loads the K <= HEAVY_WGS
+// slice sums one per lane: both need a workgroup as wide as the queue
+static_assert(MSM_THREADS == (int)HEAVY_WGS, "heavy-bucket queue header is cleared / combined by one lane per K4h workgroup");
 
 __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kernel(const uint32_t* __restrict__ srs, const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ gstart, uint32_t* __restrict__ partials,
@@ -1669,7 +1672,7 @@ static MsmPlan make_plan(size_t n, int c)
 // the then per-level fold / slice chain bumped rows + columns + slices per window past it into the next page.)
 struct MsmCarve {
     size_t digits, signs, histA, histB, binstart, bintot, tmp_entries, gstart, totals, heavy, sorted, partials, buckets, arena, segs, texp, end;
-    size_t chunks_cap;
+    size_t chunks_cap, histB_bytes;
 };
 static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
 {
@@ -1680,7 +1683,9 @@ static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
     L.digits = p;      p += al(wmax * n * 2);
     L.signs = p;       p += al(wmax * ((n + 63) / 64) * 8);      // sign bits of 17-bit windows
     L.histA = p;       p += al(nw * P.slices * 1024 * 4);        // pass-A histogram / cursors (<= 1024 bins)
-    L.histB = p;       p += al((size_t)MSM_MAX_JOBS * 1024 * SORTB_MAX_PARTS * 128 * 4); // pass-B piece counts (table mode: <= MSM_MAX_JOBS groups)
+    // pass-B piece counts: read only when heavy bins are cut into pieces (table mode, n * windows >= 2^21 digits, <= MSM_MAX_JOBS groups): nothing for smaller MSMs
+    L.histB_bytes = (uint64_t)n * nw >= ((uint64_t)1 << 21) ? (size_t)MSM_MAX_JOBS * 1024 * SORTB_MAX_PARTS * 128 * 4 : 0;
+    L.histB = p;       p += al(L.histB_bytes);
     L.binstart = p;    p += al(nw * 1024 * 4 + 256);
     L.bintot = p;      p += al(nw * 1024 * 4 + 256);
     L.tmp_entries = p; p += al(nw * n * 4);                      // pass-A output
@@ -1924,7 +1929,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     else if (table) {
         // large MSMs: eight pieces per bin (one more launch, ~8 us on the front; small MSMs are chains of dependent launches and keep one)
         static const int parts_env = [] { const char* e = getenv("BBGPU_SORTB_PARTS"); return e ? std::min((int)SORTB_MAX_PARTS, std::max(1, atoi(e))) : 0; }(); // tuning knob
-        const uint32_t parts = parts_env ? (uint32_t)parts_env : (((uint64_t)n * nw1 >= ((uint64_t)1 << 21) && G <= MSM_MAX_JOBS) ? SORTB_MAX_PARTS : 1u);
+        uint32_t parts = parts_env ? (uint32_t)parts_env : (((uint64_t)n * nw1 >= ((uint64_t)1 << 21) && G <= MSM_MAX_JOBS) ? SORTB_MAX_PARTS : 1u);
+        if ((size_t)G * sort_bins * parts * 128 * 4 > LY.histB_bytes) parts = 1; // the workspace keeps the piece counts only for large MSMs (carve)
         if (parts > 1) sortB_count_kernel<SORT_THREADS><<<dim3(sort_bins, G, parts), SORT_THREADS, 0, st>>>(tmp_entries, binstart, bases, histB, sort_bins, parts);
         sortB_staged_kernel<SORT_THREADS><<<dim3(sort_bins, G, parts), SORT_THREADS, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb, histB, parts);
     } else sortB_staged_kernel<256><<<dim3(sort_bins, G), 256, 0, st>>>(tmp_entries, binstart, bases, sorted, gstart, sort_bins, sort_lb, P.nb, nullptr, 1u);

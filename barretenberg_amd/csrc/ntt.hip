@@ -31,6 +31,13 @@
 namespace bbgpu {
 
 using Fr = FrP;
+// Phase ablation for timing experiments: a BUILD variant like the JUNK knobs (make variant NAME=nttskip1 EXTRA=-DBBGPU_NTT_DEBUG_SKIP=1),
+// never an environment variable -- the shipped kernels have no switch that changes results.  Bit 0: skip the stages, bit 1: skip the twist / scaling products.
+#ifdef BBGPU_NTT_DEBUG_SKIP
+constexpr uint32_t NTT_DEBUG_SKIP = BBGPU_NTT_DEBUG_SKIP;
+#else
+constexpr uint32_t NTT_DEBUG_SKIP = 0;
+#endif
 constexpr int NTT_VMAX = 48;                 // lazy value bound inside one pass: 6 + 3 * 12 stages + slack
 using FrL = Fe<Fr, 1, NTT_VMAX>;             // LDS-resident element
 // The fused pass keeps LAZIER limbs in LDS (round 3): up to 4 U.  A radix-2^2 group then needs two renormalisations instead of four -- the
@@ -115,7 +122,6 @@ struct NttPassArgs {
     uint32_t b_fast;          // 1: consecutive threads walk b first (column pass), 0: a first (row pass)
     uint32_t half_tile;       // host: launch the 256-thread instance (tiles of 1024 elements)
     uint32_t store_b_fast;    // fused kernel: the same choice for the STORE (1 when the b index is the contiguous one on the output side)
-    uint32_t debug_skip;      // timing experiments only (BBGPU_NTT_SKIP): 1 = skip stages, 2 = skip twist/post multiplies
     uint32_t xcd_remap;       // 1: contiguous tile range per XCD (see ntt_pass_kernel)
     uint32_t batch;           // transforms in this launch (blockIdx.y): transform j works on in + j * in_bstride -> out + j * out_bstride
     size_t in_bstride, out_bstride; // in words
@@ -165,7 +171,7 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
     // Intermediate sums stay lazy (no renormalisation between the two stages); same multiplies as radix-2, half the LDS
     // traffic and half the barriers.
     const uint32_t half = S >> 1;
-    uint32_t s = (A.debug_skip & 1) ? A.log_s : 0;
+    uint32_t s = (NTT_DEBUG_SKIP & 1) ? A.log_s : 0;
     for (; s + 1 < A.log_s; s += 2) {
         const uint32_t m = 1u << s, quarter = S >> 2, ngr = cols * quarter;
         for (uint32_t gq = tid; gq < ngr; gq += NTT_THREADS) {
@@ -265,7 +271,7 @@ template <int FLAGS> __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_ker
         for (int l = 0; l < NL; l++) x.d[l] = lds[l * E + c * S + lds_pos(k)];
         const size_t gidx = (size_t)k * A.out_sa + (size_t)b * A.out_sb;
         uint32_t w[8];
-        if ((A.debug_skip & 2) != 0) {
+        if ((NTT_DEBUG_SKIP & 2) != 0) {
             pack(assume_bound<1, 2>(x), w);
         } else if constexpr (FLAGS & 2) {
             const uint32_t ex = b * k; // < n
@@ -308,7 +314,7 @@ template <int FLAGS, int L> __device__ __forceinline__ void ntt_finish_store(con
     static_assert(L <= 6, "the twist / scaling product takes limbs up to 6 U");
     const size_t gidx = (size_t)k * A.out_sa + (size_t)b * A.out_sb;
     uint32_t w[8];
-    if ((A.debug_skip & 2) != 0) {
+    if ((NTT_DEBUG_SKIP & 2) != 0) {
         pack(assume_bound<L, 2>(x), w);
     } else if constexpr ((FLAGS & 2) && (FLAGS & 32)) {
         // one multiplication per element: the twist factor comes from a table as large as the vector, read exactly like the output is written
@@ -408,7 +414,7 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
         const uint32_t q = bitrev(t, A.log_s - 2), cb = c * S;
         const auto z0 = exact_limbs(x[0]), z1 = exact_limbs(x[2]), z2 = exact_limbs(x[1]), z3 = exact_limbs(x[3]); // unpack() / products: exact limbs
         FrS y0, y1, y2, y3;
-        if (A.debug_skip & 1) {
+        if (NTT_DEBUG_SKIP & 1) {
             y0 = z0; y1 = z1; y2 = z2; y3 = z3;
         } else {
             const auto a0 = add(z0, z1);                                   // 2 U
@@ -436,7 +442,7 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
     // ---- B: middle stage pairs in LDS ----------------------------------------------------------------------------------------
     const bool odd = (A.log_s & 1) != 0;
     const uint32_t last_s = odd ? A.log_s - 1 : A.log_s - 2; // first stage of the part fused with the store
-    uint32_t s = (A.debug_skip & 1) ? last_s : 2;
+    uint32_t s = (NTT_DEBUG_SKIP & 1) ? last_s : 2;
     for (; s < last_s; s += 2) {
         const uint32_t m = 1u << s;
         for (uint32_t gq = tid; gq < ngr; gq += THREADS) {
@@ -484,7 +490,7 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
                 x3.d[l] = lds[l * E + cb + lds_pos(j + 3 * m)];
             }
             const uint32_t b = b0 + c;
-            if (A.debug_skip & 1) {
+            if (NTT_DEBUG_SKIP & 1) {
                 ntt_finish_store<FLAGS>(A, x0, j, b);
                 ntt_finish_store<FLAGS>(A, x1, j + m, b);
                 ntt_finish_store<FLAGS>(A, x2, j + 2 * m, b);
@@ -511,7 +517,7 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
                 y.d[l] = lds[l * E + cb + lds_pos(j + half)];
             }
             const uint32_t b = b0 + c;
-            if (A.debug_skip & 1) {
+            if (NTT_DEBUG_SKIP & 1) {
                 ntt_finish_store<FLAGS>(A, x, j, b);
                 ntt_finish_store<FLAGS>(A, y, j + half, b);
             } else {
@@ -933,7 +939,6 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
         static const int remap = [] { const char* e = getenv("BBGPU_NTT_XCD"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force
         A.xcd_remap = remap >= 0 ? (uint32_t)remap : (log2n >= 20 ? 1u : 0u);
     }
-    if (const char* e = getenv("BBGPU_NTT_SKIP")) A.debug_skip = (uint32_t)atoi(e);
     A.lo_bits = D->lo_bits;
     A.twist_lo = D->twist_lo[inverse];
     A.twist_hi = D->twist_hi[inverse];

@@ -741,9 +741,9 @@ PlonkProver* get(int h)
 
 } // namespace
 
-void plonk_release_all()
+std::mutex& plonk_mutex() { return g_pmu; }
+void plonk_release_all_locked()
 {
-    std::lock_guard<std::mutex> lk(g_pmu);
     for (auto*& p : g_provers) {
         delete p;
         p = nullptr;

@@ -282,7 +282,7 @@ def plonk_leg(G, args, gates=65536, reps=10):
             import tempfile
             with tempfile.NamedTemporaryFile(suffix=".json") as tf:
                 r2 = subprocess.run([exe_gpu, "prove", str(gates)], cwd=ROOT, capture_output=True, text=True,
-                                    env=dict(os.environ, OMP_NUM_THREADS=str(threads), BB_WARM_PROOFS="2", BBGPU_SHIM_PROFILE=tf.name))
+                                    env=dict(os.environ, OMP_NUM_THREADS=str(threads), BB_WARM_PROOFS="2", BBGPU_SHIM_PROFILE=tf.name, BBGPU_SHIM_STRICT="1"))
                 m2 = re.search(r"construct_proof ([0-9.]+) ms", r2.stderr)
                 try:
                     prof = json.loads(open(tf.name).read().strip().split("\n")[0])

@@ -11,7 +11,9 @@
  *   MSM results are returned NORMALISED: z = fq::one, x,y canonical (what batched_scalar_multiplications hands the
  *   prover, scalar_multiplication.cpp:765; any Jacobian representative is legal for pippenger(), :457-476)
  * All functions return BBGPU_OK (0) or a negative error code; bbgpu_last_error() describes the last failure of the
- * calling thread.  There is NO CPU fallback inside this library: if no GPU / no code object, calls fail loudly.
+ * calling thread.  The GPU entry points have NO CPU fallback: if no GPU / no code object / no memory, they fail loudly.  The reference's
+ * C++ signatures cannot report an error, so the C++ shim -- and only it -- answers a failed call with the bbgpu_host_* entries at the
+ * end of this header (SURVEY 8b "the C++ shim must turn non-zero into CPU fallback"); BBGPU_SHIM_STRICT=1 makes it abort instead.
  */
 #ifndef BBGPU_H
 #define BBGPU_H
@@ -28,7 +30,9 @@ enum {
     BBGPU_ERR_HIP = -1,   /* a HIP runtime call failed (no device, out of memory, launch failure) */
     BBGPU_ERR_SIZE = -2,  /* size not supported (NTT: n must be 2^k, 2 <= n <= 2^28 = the two-adicity of the field) */
     BBGPU_ERR_ARG = -3,   /* null pointer / bad enum / unknown handle */
-    BBGPU_ERR_STATE = -4  /* library not initialised */
+    BBGPU_ERR_STATE = -4, /* library not initialised / every MSM slot in flight / a table that lacks what the call needs */
+    BBGPU_ERR_LOST = -5   /* an IN-PLACE host-buffer call failed while its result was being copied back: the caller's buffer may hold a mixture of
+                             input and output (the one failure the shim cannot answer with a host computation) */
 };
 
 /* polynomial_arithmetic.hpp:27-41: which member of the fft family */
@@ -276,6 +280,20 @@ int bbgpu_plonk_last_timing(int prover, double ms_out[4]);     /* construct_proo
 int bbgpu_plonk_prover_destroy(int prover);
 /* challenge.hpp:64-112 recomputed from a finished proof: gamma, beta, alpha, z (4 limbs each).  Host only, no GPU needed. */
 int bbgpu_plonk_challenges_from_proof(const uint64_t proof[BBGPU_PLONK_PROOF_WORDS], uint64_t out[16]);
+
+/* ---- host fallbacks of the drop-in boundary -----------------------------------------------------------------------
+ * The reference API has no error channel (assert.hpp:13-23; batched_scalar_multiplications prints and returns, scalar_multiplication.cpp:680-684),
+ * so a GPU call that fails at run time -- no device, an allocation refused on a shared GPU, a launch failure -- must not stop the prover:
+ * shim/bb_shim.cpp logs the library's error once and computes the same result with these entries (csrc/host_fallback.hpp: textbook bucket
+ * method / radix-2 transform / O(n) loops on the library's own host field code, a few std::threads; never oracle/).  They make no HIP call,
+ * take no lock and keep no state (re-entrant), accept what the GPU entries accept (any representative below 2^256) and return the same bytes
+ * (canonical; MSM results normalised).  The GPU entries above never call them. */
+int bbgpu_host_msm_g1(const uint64_t* scalars, const uint64_t* points, size_t n, int plain_table /* 0: 2n-entry endo table, 1: n-entry table */, uint64_t out[12]);
+int bbgpu_host_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant);
+int bbgpu_host_fr_evaluate(const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4]);
+int bbgpu_host_kate_opening(const uint64_t* src, uint64_t* dest, size_t n, const uint64_t z[4], uint64_t f_of_z[4]);
+int bbgpu_host_lagrange_l1_fft(uint64_t* l_1, size_t n_src, size_t n_target);
+int bbgpu_host_divide_by_pseudo_vanishing(uint64_t* coeffs, size_t n_src, size_t n_target);
 
 /* ---- device self-test: known-answer entry points for the field and group layer ------------------------------------
  * One GPU lane per case runs the device arithmetic every kernel is built from (csrc/fe.hpp incl. the gfx950 asm products, csrc/g1.hpp);

@@ -689,7 +689,7 @@ def test_reference_prover_runs_on_gpu_bit_exact(golden, gates, build):
     srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
     if not (os.path.exists(exe) and os.path.exists(srs)):
         pytest.fail("oracle/_ref/%s or its transcript is missing: the config-5 checker must travel with the repo (built by __graft_entry__.build() in the build container); a -m gpu run without it has lost its strongest parity evidence" % build)
-    env = dict(os.environ, OMP_NUM_THREADS="16")  # the prover's own CPU loops: do not spawn one thread per host core of the box
+    env = dict(os.environ, OMP_NUM_THREADS="16", BBGPU_SHIM_STRICT="1")  # the prover's own CPU loops: do not spawn one thread per host core of the box
     r = subprocess.run([exe, "prove", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     got = r.stdout.strip().split("\n")
@@ -711,7 +711,7 @@ def test_reference_prover_other_composers_on_gpu_bit_exact(golden, kind, gates):
     srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
     if not (os.path.exists(exe) and os.path.exists(srs)):
         pytest.fail("oracle/_ref/plonk_gpu_full or its transcript is missing: the config-5 checker must travel with the repo (built by __graft_entry__.build() in the build container); a -m gpu run without it has lost its strongest parity evidence")
-    env = dict(os.environ, OMP_NUM_THREADS="16", BB_CIRCUIT=kind)
+    env = dict(os.environ, OMP_NUM_THREADS="16", BB_CIRCUIT=kind, BBGPU_SHIM_STRICT="1")
     r = subprocess.run([exe, "prove", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     got = r.stdout.strip().split("\n")
@@ -731,7 +731,7 @@ def test_reference_composer_to_resident_prover_adapter(golden, kind, gates):
     srs = os.path.join(root, "oracle", "_ref", "transcript.dat")
     if not (os.path.exists(exe) and os.path.exists(srs)):
         pytest.fail("oracle/_ref/plonk_gpu or its transcript is missing: the config-5 checker must travel with the repo (built by __graft_entry__.build() in the build container); a -m gpu run without it has lost its strongest parity evidence")
-    env = dict(os.environ, OMP_NUM_THREADS="16")
+    env = dict(os.environ, OMP_NUM_THREADS="16", BBGPU_SHIM_STRICT="1")
     if kind != "standard":
         env["BB_CIRCUIT"] = kind
     r = subprocess.run([exe, "adapter", str(gates)], cwd=root, capture_output=True, text=True, timeout=300, env=env)

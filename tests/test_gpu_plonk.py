@@ -257,7 +257,7 @@ def test_commitments_at_infinity(gpu, srs65536, golden):
         if not os.path.exists(exe):
             pytest.fail("oracle/_ref/plonk_cpu is missing: the reference's Verifier is the judge of this test")
         r = subprocess.run([exe, "verify", "32"], input="\n".join(lines) + "\n", cwd=ROOT, capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, OMP_NUM_THREADS="4", BB_CIRCUIT="zerowire"))
+                           env=dict(os.environ, OMP_NUM_THREADS="4", BB_CIRCUIT="zerowire", BBGPU_SHIM_STRICT="1"))
         assert r.returncode == 0 and r.stdout.strip() == "verified 1", (r.stdout, r.stderr[-500:])
     finally:
         prover.destroy()
@@ -265,7 +265,7 @@ def test_commitments_at_infinity(gpu, srs65536, golden):
     exe = os.path.join(ROOT, "oracle", "_ref", "plonk_gpu")
     if not os.path.exists(exe):
         pytest.fail("oracle/_ref/plonk_gpu is missing")
-    r = subprocess.run([exe, "trace", "32"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="4", BB_CIRCUIT="zerowire"))
+    r = subprocess.run([exe, "trace", "32"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="4", BB_CIRCUIT="zerowire", BBGPU_SHIM_STRICT="1"))
     shim = dict(ln.split() for ln in r.stdout.strip().split("\n") if len(ln.split()) == 2)
     assert shim.get("verified") == "1", (r.stdout[-400:], r.stderr[-400:])
     for k in ("W_R", "W_O"):

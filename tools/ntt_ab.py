@@ -13,4 +13,4 @@ for kind in ("fft", "coset_fft", "ifft"):
     e0.record(s)
     for _ in range(20): G.ntt_device(d.data_ptr(), n, kind, stream=s.cuda_stream)
     e1.record(s); torch.cuda.synchronize()
-    print("skip=%s %-10s %.4f ms" % (os.environ.get("BBGPU_NTT_SKIP", "0"), kind, e0.elapsed_time(e1) / 20))
+    print("lib=%s %-10s %.4f ms" % (os.path.basename(os.environ.get("BBGPU_LIB", "libbbgpu.so")), kind, e0.elapsed_time(e1) / 20))
