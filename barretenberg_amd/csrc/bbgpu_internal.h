@@ -33,14 +33,30 @@ struct MsmWorkspace {
     int ensure(size_t bytes);
     void release();
 };
+// One MSM of a slot may be issued as several PIECES -- point ranges against different segments of the window tables (an SRS above 2^20 points keeps
+// one table per <= 2^20-point segment, capi.hip), enqueued back to back on the slot's stream and sharing its workspace in stream order; every piece
+// writes its own 64-slot groups of the pinned result array and the host adds the piece sums (a sum over a range of points is a plain term of the MSM).
+struct MsmPiece {
+    uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0;
+    uint32_t hout_group = 0; // first 64-slot group of this piece in ws.h_out
+    bool trivial = false;
+};
+constexpr int MSM_MAX_JOBS = 4;        // MSMs over the same points issued as one batch (one bucket set each)
+constexpr int MSM_MAX_PIECES = 32;      // per slot
+constexpr uint32_t MSM_HOUT_GROUPS = 128; // 64-slot groups of the pinned result array (pieces x jobs, or the windows of one table-less piece)
 struct MsmSlot {
     MsmWorkspace ws;
+    MsmPiece piece[MSM_MAX_PIECES];
+    int npieces = 0;
+    bool append = false; // set by the caller before an issue: add a piece to the MSM already issued on this slot instead of starting a new one
+    int helper = -1;     // capi.hip: a second slot (own stream and workspace) that carries every other piece of this ticket, or -1
+    bool is_helper = false; // this slot is pending as the helper of another ticket: collected through its owner only
     hipStream_t stream = nullptr; // the slot's own stream (used when the caller passes none)
     hipEvent_t done = nullptr;
     hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     bool pending = false, trivial = false, timed = false, timed_light = false;
     size_t n = 0;
-    uint32_t c = 0, nw = 0, wb = 0, hbits = 0, lbits = 0, jobs = 1;
+    uint32_t jobs = 1;
     uint64_t acc_seq = 0; // position of this MSM's accumulation in the process-wide sequence of timed accumulations (0 = none)
     // set by the caller before an issue: other MSMs are in flight, so this one is paced by the instructions it issues, not by its dependent chain
     // (msm_issue_batch then takes longer chunks and the two-step row / column sums)

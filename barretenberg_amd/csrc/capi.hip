@@ -38,9 +38,17 @@ struct SrsEntry {
     size_t n;
     uint32_t* d_srs;
     bool live;
-    uint32_t* d_tab = nullptr; // pre-shifted window tables [tab_W][n], or null: the address window 0 has (or would have)
-    uint32_t* d_tab_alloc = nullptr; // the allocation itself: starts at window tab_wb when only a share of the windows is kept
-    int tab_c = 0, tab_W = 0, tab_wb = 0, tab_we = 0; // windows [tab_wb, tab_we) are resident
+    // Pre-shifted window tables, one per SEGMENT of at most 2^24 / W points (the sorted entries carry a 24-bit table row: 2^20 points at 15 windows).
+    // A larger SRS keeps several segments of equal length and an MSM over it runs as one piece per segment it touches, the piece sums added on
+    // the host -- the point-range split of scalar_multiplication.cpp:703-738 inside one GPU.  Empty: no tables (per-window bucket sets).
+    struct TabSeg {
+        size_t first = 0, n = 0;          // points [first, first + n) of the entry
+        uint32_t* d_tab = nullptr;       // [tab_W][n] rows of 64 bytes: the address window 0 has (or would have)
+        uint32_t* d_tab_alloc = nullptr; // the allocation itself: starts at window tab_wb when only a share of the windows is kept
+    };
+    std::vector<TabSeg> segs;
+    bool has_tab() const { return !segs.empty(); }
+    int tab_c = 0, tab_W = 0, tab_wb = 0, tab_we = 0; // windows [tab_wb, tab_we) are resident (the same for every segment)
     // Address-keyed lookups are only trusted after a CONTENT check: one 64-bit hash per base point (the even table entry the kernels
     // read), taken when the table was uploaded.  A lookup re-hashes the first, the last and up to 14 evenly spaced rows of the range
     // the caller passed (it never touches host memory outside that range: the old table may have been freed) and compares.
@@ -89,6 +97,7 @@ struct Context {
     bool host_env_read = false;
     int share_rank = 0, share_world = 1; // window share of the tables built from now on (bbgpu_set_table_share)
     int point_world = 1;                 // tables built from now on hold 1 / point_world of the points of a larger MSM (bbgpu_set_point_share)
+    hipEvent_t helper_dep[NSLOT] = {};   // orders a helper slot's stream behind the caller's stream (issue_ticket)
     // Workspaces shared by every caller (NTT scratch, polynomial temporaries): users on different streams are chained by this event
     hipEvent_t shared_done = nullptr;
     hipStream_t shared_last = nullptr;
@@ -293,8 +302,10 @@ void free_entry(SrsEntry& e)
     // an asynchronous MSM may still be reading the table: drain the device first (rare path)
     (void)hipDeviceSynchronize();
     if (e.d_srs) (void)hipFree(e.d_srs);
-    if (e.d_tab_alloc) (void)hipFree(e.d_tab_alloc);
-    e.d_srs = e.d_tab = e.d_tab_alloc = nullptr;
+    for (auto& sg : e.segs)
+        if (sg.d_tab_alloc) (void)hipFree(sg.d_tab_alloc);
+    e.segs.clear();
+    e.d_srs = nullptr;
     e.live = false;
     e.row_hash.clear();
     e.row_hash.shrink_to_fit();
@@ -340,7 +351,13 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
     if (g_ctx.point_world > 1 && c == 17 && n < ((size_t)1 << 18)) c = 16;
     if (const char* ev = getenv("BBGPU_TABLE_C")) c = std::min(17, std::max(4, atoi(ev))); // tuning knob: window size of the tables
     const int W = msm_num_windows(c);
-    const bool want_tab = g_ctx.precompute && n >= 1024 && (uint64_t)n * W <= ((uint64_t)1 << 24);
+    // segments: as few as the 24-bit row index allows, equal lengths (multiples of 8: the sort reads eight digits per load).  One up to 2^20 points;
+    // beyond that the tables are kept up to BBGPU_TABLE_MAX_BYTES (default 64 GiB = 2^26 points) -- larger tables fall back to per-window bucket sets
+    static const uint64_t tab_max_bytes = [] { const char* v = getenv("BBGPU_TABLE_MAX_BYTES"); return v ? strtoull(v, nullptr, 0) : (uint64_t)64 << 30; }();
+    const size_t seg_cap = (size_t)((((uint64_t)1 << 24) / (uint64_t)W) & ~(uint64_t)7);
+    const size_t nseg = (n + seg_cap - 1) / seg_cap;
+    const size_t seg_n = nseg <= 1 ? n : ((((n + nseg - 1) / nseg) + 7) & ~(size_t)7);
+    const bool want_tab = g_ctx.precompute && n >= 1024 && (nseg == 1 || ((uint64_t)n * W * 64 <= tab_max_bytes && nseg <= 2 * (size_t)MSM_MAX_PIECES));
     // a rank of an N-way row split touches windows [floor(W r / N), ceil(W (r + 1) / N)) only (bbgpu_set_table_share)
     const int twb = (int)((int64_t)W * g_ctx.share_rank / g_ctx.share_world);
     const int twe = (int)(((int64_t)W * (g_ctx.share_rank + 1) + g_ctx.share_world - 1) / g_ctx.share_world);
@@ -361,10 +378,17 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
         }
     }
     if (want_tab) {
-        int rc = srs_build_table(d_srs, n, c, W, twb, twe, &e.d_tab_alloc, &e.d_tab, g_ctx.stream);
-        if (rc) {
-            (void)hipFree(d_srs);
-            return rc;
+        for (size_t first = 0; first < n; first += seg_n) {
+            SrsEntry::TabSeg sg;
+            sg.first = first;
+            sg.n = std::min(seg_n, n - first);
+            int rc = srs_build_table(d_srs + first * 16, sg.n, c, W, twb, twe, &sg.d_tab_alloc, &sg.d_tab, g_ctx.stream);
+            if (rc) {
+                for (auto& o : e.segs) (void)hipFree(o.d_tab_alloc);
+                (void)hipFree(d_srs);
+                return rc;
+            }
+            e.segs.push_back(sg);
         }
         e.tab_c = c;
         e.tab_W = W;
@@ -385,11 +409,11 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
 }
 int entry_windows(const SrsEntry& e, size_t n)
 {
-    return e.d_tab ? e.tab_W : msm_num_windows(msm_choose_c(n ? n : 1));
+    return e.has_tab() ? e.tab_W : msm_num_windows(msm_choose_c(n ? n : 1));
 }
 bool windows_resident(const SrsEntry& e, int wb, int we)
 {
-    if (!e.d_tab || (wb >= e.tab_wb && we <= e.tab_we)) return true;
+    if (!e.has_tab() || (wb >= e.tab_wb && we <= e.tab_we)) return true;
     set_error("windows [%d, %d) requested, this table keeps [%d, %d) of %d (bbgpu_set_table_share)", wb, we, e.tab_wb, e.tab_we, e.tab_W);
     return false;
 }
@@ -399,24 +423,161 @@ int pick_slot()
 {
     int order[Context::NSLOT] = { g_ctx.next_slot, g_ctx.next_slot ^ 1 };
     for (int k = 2; k < Context::NSLOT; k++) order[k] = k;
-    bool others = false; // another MSM in flight: the one about to be issued shares the chip (MsmSlot::throughput)
-    for (int k = 0; k < Context::NSLOT; k++) others = others || g_ctx.slot[k].pending;
     for (int k = 0; k < Context::NSLOT; k++)
-        if (!g_ctx.slot[order[k]].pending) {
-            g_ctx.slot[order[k]].throughput = others;
-            return order[k];
-        }
+        if (!g_ctx.slot[order[k]].pending) return order[k];
     set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
     return -1;
 }
-int issue_on_entry(MsmSlot& S, const SrsEntry& e, size_t off, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st)
+// up to `want` slots that are not in flight, for the synchronous (host-pointer) entry points: they take what is free instead of insisting on
+// slots 0 / 1, so a caller that holds asynchronous tickets -- or other threads doing so -- never makes pippenger() fail (the reference calls it
+// from inside an OpenMP region, scalar_multiplication.cpp:731-738; calls are serialised by the library mutex, not refused)
+int free_slots(int* out, int want)
 {
-    // the synchronous entry points use slots 0 / 1 directly (the point ranges of a host-pointer MSM, the jobs of a host-pointer batch): the same hint as pick_slot()
-    bool others = false;
-    for (int k = 0; k < Context::NSLOT; k++) others = others || (&g_ctx.slot[k] != &S && g_ctx.slot[k].pending);
-    S.throughput = others;
+    int got = 0;
+    for (int k = 0; k < Context::NSLOT && got < want; k++)
+        if (!g_ctx.slot[k].pending) out[got++] = k;
+    return got;
+}
+int ensure_slot_stream(MsmSlot& S)
+{
+    if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    return BBGPU_OK;
+}
+
+// The pieces of the point range [off, off + n) of an entry: one per table segment it touches (one in all without tables or inside one segment).
+struct PointPiece {
+    const SrsEntry::TabSeg* seg; // null: no tables
+    size_t off_in_seg, first, len; // first: offset inside the call's range (and its scalars)
+};
+int split_pieces(const SrsEntry& e, size_t off, size_t n, PointPiece* out, int cap)
+{
+    if (!e.has_tab()) {
+        out[0] = PointPiece{ nullptr, off, 0, n };
+        return 1;
+    }
+    if (n == 0) { // nothing to add up: any segment will do
+        out[0] = PointPiece{ &e.segs[0], 0, 0, 0 };
+        return 1;
+    }
+    int cnt = 0;
+    for (const auto& sg : e.segs) {
+        const size_t lo = std::max(off, sg.first), hi = std::min(off + n, sg.first + sg.n);
+        if (lo >= hi) continue;
+        if (cnt == cap) return -1;
+        out[cnt++] = PointPiece{ &sg, lo - sg.first, lo - off, hi - lo };
+    }
+    return cnt;
+}
+constexpr int MAX_POINT_PIECES = 2 * MSM_MAX_PIECES;
+
+bool others_pending(const MsmSlot* a, const MsmSlot* b = nullptr)
+{
+    for (int k = 0; k < Context::NSLOT; k++)
+        if (&g_ctx.slot[k] != a && &g_ctx.slot[k] != b && g_ctx.slot[k].pending) return true;
+    return false;
+}
+// collects whatever slot t (and its helper) still has in flight and forgets it: error paths
+void drain_ticket(int t)
+{
+    MsmSlot& S = g_ctx.slot[t];
+    host::Xyzz dump[MSM_MAX_JOBS];
+    if (S.helper >= 0) {
+        MsmSlot& H = g_ctx.slot[S.helper];
+        if (H.pending) (void)msm_finish_batch(H, dump, nullptr);
+        H.is_helper = false;
+        S.helper = -1;
+    }
+    if (S.pending) (void)msm_finish_batch(S, dump, nullptr);
+}
+// Issues `jobs` MSMs (one scalar vector each) over points [off, off + n) of entry e, windows [wb, we), on slot t; `st` = the caller's stream or the
+// slot's own.  Inside one table segment (every SRS up to 2^20 points) that is one pass through the kernels.  A range that spans several segments
+// is issued as one PIECE per segment, dealt alternately to slot t and -- when one is free -- a HELPER slot with its own stream and workspace, so
+// that the digit / sort front of piece k + 1 runs beside the accumulation of piece k exactly as two consecutive MSMs do; the helper
+// is ordered behind the producer of the scalars by an event when the caller gave a stream.  The ticket stays slot t: finish_ticket() adds up
+// both slots' pieces.
+int issue_ticket(int t, const SrsEntry& e, size_t off, const uint64_t* const* d_scalars_v, int jobs, size_t n, int wb, int we, hipStream_t st)
+{
+    MsmSlot& S = g_ctx.slot[t];
+    S.helper = -1;
+    S.append = false;
     if (!windows_resident(e, wb, we)) return BBGPU_ERR_STATE;
-    return msm_issue(S, e.d_srs + off * 16, e.d_tab ? e.d_tab + off * 16 : nullptr, e.n, e.tab_c, d_scalars, n, wb, we, st, g_ctx.timing);
+    PointPiece pc[MAX_POINT_PIECES];
+    const int np = split_pieces(e, off, n, pc, MAX_POINT_PIECES);
+    if (np < 0) {
+        set_error("MSM of %zu points spans more than %d table segments", n, MAX_POINT_PIECES);
+        return BBGPU_ERR_SIZE;
+    }
+    if (np == 1) {
+        S.throughput = others_pending(&S);
+        const uint32_t* tab = pc[0].seg ? pc[0].seg->d_tab + pc[0].off_in_seg * 16 : nullptr;
+        return msm_issue_batch(S, e.d_srs + off * 16, tab, pc[0].seg ? pc[0].seg->n : e.n, e.tab_c, d_scalars_v, jobs, n, wb, we, st, g_ctx.timing);
+    }
+    // several pieces: a helper slot for every other one, if any slot is free
+    int h = -1;
+    {
+        int order[Context::NSLOT], cnt = 0;
+        if (t < 2) order[cnt++] = t ^ 1; // the pair the two-deep pipeline of large MSMs uses
+        for (int k = Context::NSLOT - 1; k >= 2; --k) order[cnt++] = k; // from the top: the low ones are what the next tickets take
+        for (int k = 0; k < cnt && h < 0; k++)
+            if (order[k] != t && !g_ctx.slot[order[k]].pending) h = order[k];
+    }
+    MsmSlot* H = h >= 0 ? &g_ctx.slot[h] : nullptr;
+    if (H) {
+        if (int rc = ensure_slot_stream(*H)) return rc;
+        if (st != S.stream) { // the caller's stream carries the producer of the scalars: the helper's stream starts behind what is enqueued there now
+            if (!g_ctx.helper_dep[h]) CHK(hipEventCreateWithFlags(&g_ctx.helper_dep[h], hipEventDisableTiming));
+            CHK(hipEventRecord(g_ctx.helper_dep[h], st));
+            CHK(hipStreamWaitEvent(H->stream, g_ctx.helper_dep[h], 0));
+        }
+        H->helper = -1;
+    }
+    int issued[2] = { 0, 0 };
+    int rc = BBGPU_OK;
+    for (int k = 0; k < np && rc == BBGPU_OK; k++) {
+        const int side = (H && (k & 1)) ? 1 : 0;
+        MsmSlot& T = side ? *H : S;
+        const uint64_t* sv[MSM_MAX_JOBS];
+        for (int j = 0; j < jobs; j++) sv[j] = d_scalars_v[j] + pc[k].first * 4;
+        T.append = issued[side] > 0;
+        T.throughput = true; // pieces share the chip with each other
+        rc = msm_issue_batch(T, e.d_srs + (off + pc[k].first) * 16, pc[k].seg->d_tab + pc[k].off_in_seg * 16, pc[k].seg->n, e.tab_c, sv, jobs, pc[k].len, wb, we,
+                             side ? H->stream : st, g_ctx.timing);
+        if (rc == BBGPU_OK) issued[side]++;
+    }
+    if (H && issued[1] > 0) {
+        H->is_helper = true;
+        S.helper = h;
+    }
+    if (rc != BBGPU_OK) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        drain_ticket(t);
+        memcpy(g_err, keep, sizeof(keep));
+    }
+    return rc;
+}
+int issue_on_entry(int t, const SrsEntry& e, size_t off, const uint64_t* d_scalars, size_t n, int wb, int we, hipStream_t st)
+{
+    return issue_ticket(t, e, off, &d_scalars, 1, n, wb, we, st);
+}
+// waits for ticket t and adds up its pieces: one point per job
+int finish_ticket(int t, host::Xyzz* results, MsmTiming* timing)
+{
+    MsmSlot& S = g_ctx.slot[t];
+    const uint32_t jobs = S.jobs;
+    const int h = S.helper;
+    S.helper = -1;
+    int rc = msm_finish_batch(S, results, timing);
+    if (h >= 0) {
+        MsmSlot& H = g_ctx.slot[h];
+        host::Xyzz more[MSM_MAX_JOBS];
+        const int rc2 = msm_finish_batch(H, more, nullptr);
+        H.is_helper = false;
+        if (rc == BBGPU_OK) rc = rc2;
+        if (rc == BBGPU_OK)
+            for (uint32_t j = 0; j < jobs; j++) results[j] = host::g1_add(results[j], more[j]);
+    }
+    return rc;
 }
 
 // does the host range [points, points + n) still hold what entry e was uploaded from (rows off .. off + n)?
@@ -487,10 +648,6 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         set_error("null scalars/points");
         return BBGPU_ERR_ARG;
     }
-    if (g_ctx.slot[0].pending) {
-        set_error("an asynchronous MSM is still in flight on slot 0: wait for it first");
-        return BBGPU_ERR_STATE;
-    }
     size_t off = 0;
     int idx = plain ? -1 : find_srs(points, n, &off);
     read_host_env();
@@ -502,6 +659,15 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         int rc = ensure_init();
         if (rc) return rc;
     }
+    // whatever slots are free (a caller -- or another thread -- may hold asynchronous tickets on any of them): two give the pipeline, one works
+    int sl[2];
+    const int ns = free_slots(sl, 2);
+    if (ns == 0) {
+        set_error("all %d MSM slots are in flight: call bbgpu_msm_g1_wait first", Context::NSLOT);
+        return BBGPU_ERR_STATE;
+    }
+    for (int k = 0; k < ns; k++)
+        if (int rc = ensure_slot_stream(g_ctx.slot[sl[k]])) return rc;
     // A table that was never registered and is too small to be an SRS (the verifier's ~20 freshly built points,
     // verifier.cpp:359-363) is used once and forgotten: caching it by address would both leak device memory per call and
     // serve stale points when the caller's vector is freed and its address reused.  Larger unknown tables are taken to be a
@@ -524,57 +690,68 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         off = 0;
     }
     const SrsEntry& e = is_transient ? transient : g_ctx.srs[idx];
-    host::Xyzz res;
-    int rc = BBGPU_OK;
-    // A large MSM is cut into point ranges that go through the two-slot pipeline like the jobs of a batch: the scalars of range k+1
-    // cross the link while the kernels of range k run, and the partial sums (group elements: the sum over a range of points is a
-    // plain term of the whole sum) are added on the host.  One 2^20-point call: 32 MiB of scalars = 0.6 ms on the link before the
-    // first kernel, against 0.15 ms for the first of four ranges (bench.py `boundary`).  BBGPU_HOST_MSM_SPLIT=1 restores one range.
+    // The call is cut into point RANGES that go through the free slots like the jobs of a batch: the scalars of range k+1 cross the link while
+    // the kernels of range k run, and the partial sums (group elements: the sum over a range of points is a plain term of the whole sum) are
+    // added on the host.  Above 2^20 points the ranges are the table segments the call touches (each at most 2^20 points with its own window
+    // tables); inside one segment a call of 2^19 points and more is cut in two -- one 2^20-point call: 32 MiB of scalars = 0.6 ms on the link
+    // before the first kernel, against 0.22 ms for the first of two ranges (bench.py `boundary`).  BBGPU_HOST_MSM_SPLIT=1 keeps one range per segment.
     static const size_t split_env = [] { const char* v = getenv("BBGPU_HOST_MSM_SPLIT"); return v ? (size_t)std::max(1, atoi(v)) : (size_t)0; }();
-    // Measured on MI355X (tools/boundary_ab.py, 2^20 points): one range 2.05-2.08 ms, two 1.77 ms, four 2.17-2.20 ms -- every range pays its
-    // own sort and bucket-reduction tail (~0.3 ms of launches that only partly hide), so two it is, the first one the smaller: its
-    // upload is the part nothing hides, and the second range's upload (0.6 ms x its share) still fits under the first one's kernels.
-    const size_t ranges = split_env ? split_env : (n >= ((size_t)1 << 19) ? 2 : 1);
-    if (ranges > 1 && !g_ctx.slot[1].pending) {
-        static const size_t first_pct = [] { const char* v = getenv("BBGPU_HOST_MSM_FIRST_PCT"); return v ? (size_t)std::min(50, std::max(5, atoi(v))) : (size_t)0; }(); // tuning knob; measured 25 / 30 / 34 / 37 / 42 %: 1.84 / 1.80 / 1.83 / 1.775 / 1.79 ms
-        const size_t base = ranges == 2 ? (((first_pct ? n * first_pct / 100 : n * 3 / 8)) & ~(size_t)7) : n / ranges;
-        uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
-        size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
-        res = host::g1_infinity();
-        auto finish = [&](size_t k) -> int {
-            host::Xyzz part;
-            int r = msm_finish(g_ctx.slot[k & 1], &part, k + 1 == ranges ? &g_ctx.last : nullptr);
-            if (r == BBGPU_OK) res = host::g1_add(res, part);
-            return r;
-        };
-        size_t issued = 0;
-        for (size_t k = 0; k < ranges && rc == BBGPU_OK; k++) {
-            const int t = (int)(k & 1);
-            MsmSlot& S = g_ctx.slot[t];
-            const size_t o = k * base, len = (k + 1 == ranges) ? n - o : base;
-            rc = grow(stage[t], cap[t], (n - (ranges - 1) * base) * 32);
-            if (rc == BBGPU_OK && !S.stream && hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) {
-                set_error("stream creation failed");
-                rc = BBGPU_ERR_HIP;
+    struct Range { size_t o, len; };
+    std::vector<Range> ranges;
+    {
+        PointPiece pc[MAX_POINT_PIECES];
+        const int np = split_pieces(e, off, n, pc, MAX_POINT_PIECES);
+        if (np < 0) {
+            if (is_transient) (void)hipFree(transient.d_srs);
+            set_error("MSM of %zu points spans more than %d table segments", n, MAX_POINT_PIECES);
+            return BBGPU_ERR_SIZE;
+        }
+        if (np > 1) {
+            for (int k = 0; k < np; k++) ranges.push_back(Range{ pc[k].first, pc[k].len });
+        } else {
+            // Measured on MI355X (tools/boundary_ab.py, 2^20 points): one range 2.05-2.08 ms, two 1.77 ms, four 2.17-2.20 ms -- every range pays its
+            // own sort and bucket-reduction tail (~0.3 ms of launches that only partly hide), so two it is, the first one the smaller: its
+            // upload is the part nothing hides, and the second range's upload (0.6 ms x its share) still fits under the first one's kernels.
+            const size_t parts = ns < 2 ? 1 : (split_env ? split_env : (n >= ((size_t)1 << 19) ? 2 : 1));
+            static const size_t first_pct = [] { const char* v = getenv("BBGPU_HOST_MSM_FIRST_PCT"); return v ? (size_t)std::min(50, std::max(5, atoi(v))) : (size_t)0; }(); // tuning knob; measured 25 / 30 / 34 / 37 / 42 %: 1.84 / 1.80 / 1.83 / 1.775 / 1.79 ms
+            const size_t base = parts == 2 ? (((first_pct ? n * first_pct / 100 : n * 3 / 8)) & ~(size_t)7) : n / parts;
+            for (size_t k = 0; k < parts; k++) {
+                const size_t o = k * base, len = (k + 1 == parts) ? n - o : base;
+                if (len) ranges.push_back(Range{ o, len });
             }
-            if (rc == BBGPU_OK) rc = host_to_device(*stage[t], scalars + o * 4, len * 32, S.stream);
-            if (rc == BBGPU_OK) rc = issue_on_entry(S, e, off + o, *stage[t], len, 0, entry_windows(e, len), S.stream);
-            if (rc == BBGPU_OK) issued = k + 1;
-            if (rc == BBGPU_OK && k >= 1) rc = finish(k - 1);
         }
-        if (rc == BBGPU_OK) rc = finish(ranges - 1);
-        else { // drain whatever is still in flight so that the slots are usable again
-            host::Xyzz dump;
-            for (size_t k = issued >= 2 ? issued - 2 : 0; k < issued; k++)
-                if (g_ctx.slot[k & 1].pending) (void)msm_finish(g_ctx.slot[k & 1], &dump, nullptr);
-        }
-    } else {
-        rc = grow(&g_ctx.d_stage, &g_ctx.stage_cap, n * 32);
-        if (rc == BBGPU_OK) rc = host_to_device(g_ctx.d_stage, scalars, n * 32, g_ctx.stream);
-        if (rc == BBGPU_OK) rc = issue_on_entry(g_ctx.slot[0], e, off, g_ctx.d_stage, n, 0, entry_windows(e, n), g_ctx.stream);
-        if (rc == BBGPU_OK) rc = msm_finish(g_ctx.slot[0], &res, &g_ctx.last);
     }
-    if (is_transient) (void)hipFree(transient.d_srs); // msm_finish has waited for the kernels
+    size_t max_len = 0;
+    for (const auto& r : ranges) max_len = std::max(max_len, r.len);
+    uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
+    size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
+    host::Xyzz res = host::g1_infinity();
+    int rc = BBGPU_OK;
+    size_t issued = 0, finished = 0;
+    auto finish = [&](size_t k) -> int {
+        host::Xyzz part;
+        int r = finish_ticket(sl[k % (size_t)ns], &part, k + 1 == ranges.size() ? &g_ctx.last : nullptr);
+        finished = k + 1;
+        if (r == BBGPU_OK) res = host::g1_add(res, part);
+        return r;
+    };
+    for (size_t k = 0; k < ranges.size() && rc == BBGPU_OK; k++) {
+        const size_t w = k % (size_t)ns;
+        if (k >= (size_t)ns) rc = finish(k - (size_t)ns); // frees this range's slot and staging buffer
+        MsmSlot& S = g_ctx.slot[sl[w]];
+        if (rc == BBGPU_OK) rc = grow(stage[w], cap[w], max_len * 32);
+        if (rc == BBGPU_OK) rc = host_to_device(*stage[w], scalars + ranges[k].o * 4, ranges[k].len * 32, S.stream);
+        if (rc == BBGPU_OK) rc = issue_on_entry(sl[w], e, off + ranges[k].o, *stage[w], ranges[k].len, 0, entry_windows(e, ranges[k].len), S.stream);
+        if (rc == BBGPU_OK) issued = k + 1;
+    }
+    while (rc == BBGPU_OK && finished < issued) rc = finish(finished);
+    if (rc != BBGPU_OK) { // drain whatever is still in flight so that the slots are usable again (the error text is the first failure's)
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        for (int k = 0; k < ns; k++) drain_ticket(sl[k]);
+        memcpy(g_err, keep, sizeof(keep));
+    }
+    if (is_transient) (void)hipFree(transient.d_srs); // the finishes have waited for the kernels
     if (rc) return rc;
     host::g1_to_normalised(res, out);
     return BBGPU_OK;
@@ -619,11 +796,12 @@ void bbgpu_shutdown(void)
     plonk_release_all_locked();
     // nothing may still be reading the pinned staging buffers or a slot's workspace when they are freed: collect what is in flight
     // (an MSM a caller never waited for, a copy queued before an error return) and drain every stream first
-    for (auto& sl : g_ctx.slot)
-        if (sl.pending) {
-            host::Xyzz dump[4];
-            (void)msm_finish_batch(sl, dump, nullptr);
-        }
+    for (int k = 0; k < Context::NSLOT; k++)
+        if (g_ctx.slot[k].pending && !g_ctx.slot[k].is_helper) drain_ticket(k);
+    for (auto& ev : g_ctx.helper_dep) {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+    }
     (void)hipStreamSynchronize(g_ctx.stream);
     for (auto& sl : g_ctx.slot)
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -635,7 +813,9 @@ void bbgpu_shutdown(void)
     g_ctx.poly_tmp_cap = 0;
     for (auto& e : g_ctx.srs) {
         if (e.live && e.d_srs) (void)hipFree(e.d_srs);
-        if (e.live && e.d_tab_alloc) (void)hipFree(e.d_tab_alloc);
+        if (e.live)
+            for (auto& sg : e.segs)
+                if (sg.d_tab_alloc) (void)hipFree(sg.d_tab_alloc);
     }
     g_ctx.srs.clear();
     for (auto& sl : g_ctx.slot) sl.release();
@@ -1260,7 +1440,10 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
     }
     const size_t n = jobs[0].num_elements;
     read_host_env();
-    if (n == 0 || n <= (size_t)g_ctx.host_msm_max || g_ctx.slot[0].pending || g_ctx.slot[1].pending) {
+    int sl[2];
+    // one at a time: tiny jobs (answered on the host), fewer than two free slots, or jobs above one table segment (each is a pipeline of its own)
+    bool one_by_one = n == 0 || n <= (size_t)g_ctx.host_msm_max || n > ((size_t)1 << 20) || free_slots(sl, 2) < 2;
+    if (one_by_one) {
         for (size_t i = 0; i < num_jobs; i++) {
             rc = msm_host_ptrs(jobs[i].scalars, jobs[i].points, jobs[i].num_elements, jobs[i].output);
             if (rc) return rc;
@@ -1268,6 +1451,8 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
         return BBGPU_OK;
     }
     if ((rc = ensure_init()) != BBGPU_OK) return rc;
+    for (int k = 0; k < 2; k++)
+        if ((rc = ensure_slot_stream(g_ctx.slot[sl[k]])) != BBGPU_OK) return rc;
     // Two-slot pipeline over the jobs of a prover round (3/1/3/2 MSMs, prover.cpp:65-122,650-658): job i+1's scalars
     // cross PCIe and its kernels are enqueued while job i's bucket-reduction tail and host finish run.
     uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
@@ -1277,7 +1462,7 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
     auto issue = [&](size_t i) -> int {
         const double q0 = tr ? now_ms() : 0;
         const int t = (int)(i & 1);
-        MsmSlot& S = g_ctx.slot[t];
+        MsmSlot& S = g_ctx.slot[sl[t]];
         if (!jobs[i].scalars || !jobs[i].points) {
             set_error("null scalars/points in job %zu", i);
             return BBGPU_ERR_ARG;
@@ -1294,30 +1479,35 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
         const double q1 = tr ? now_ms() : 0;
         int r = grow(stage[t], cap[t], n * 32);
         if (r) return r;
-        if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         if ((r = host_to_device(*stage[t], jobs[i].scalars, n * 32, S.stream)) != BBGPU_OK) return r;
         const double q2 = tr ? now_ms() : 0;
-        r = issue_on_entry(S, g_ctx.srs[idx], off, *stage[t], n, 0, entry_windows(g_ctx.srs[idx], n), S.stream);
+        r = issue_on_entry(sl[t], g_ctx.srs[idx], off, *stage[t], n, 0, entry_windows(g_ctx.srs[idx], n), S.stream);
         if (tr) fprintf(stderr, "bbgpu batch: job %zu srs %.3f, copy call %.3f, kernel launches %.3f ms\n", i, q1 - q0, q2 - q1, now_ms() - q2);
         return r;
     };
     auto finish = [&](size_t i) -> int {
         host::Xyzz res;
-        int r = msm_finish(g_ctx.slot[i & 1], &res, nullptr);
+        int r = finish_ticket(sl[i & 1], &res, nullptr);
         if (r) return r;
         host::g1_to_normalised(res, jobs[i].output);
         return BBGPU_OK;
     };
-    for (size_t i = 0; i < num_jobs; i++) {
+    for (size_t i = 0; i < num_jobs && rc == BBGPU_OK; i++) {
         const double t0 = tr ? now_ms() : 0;
-        if ((rc = issue(i)) != BBGPU_OK) return rc;
+        rc = issue(i);
         const double t1 = tr ? now_ms() : 0;
-        if (i >= 1 && (rc = finish(i - 1)) != BBGPU_OK) return rc;
+        if (rc == BBGPU_OK && i >= 1) rc = finish(i - 1);
         if (tr) fprintf(stderr, "bbgpu batch: job %zu issue %.3f ms, finish(prev) %.3f ms\n", i, t1 - t0, now_ms() - t1);
     }
     const double t2 = tr ? now_ms() : 0;
-    rc = finish(num_jobs - 1);
+    if (rc == BBGPU_OK) rc = finish(num_jobs - 1);
     if (tr) fprintf(stderr, "bbgpu batch: last finish %.3f ms\n", now_ms() - t2);
+    if (rc != BBGPU_OK) { // nothing of this call stays in flight (the error text is the first failure's)
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        for (int k = 0; k < 2; k++) drain_ticket(sl[k]);
+        memcpy(g_err, keep, sizeof(keep));
+    }
     return rc;
 }
 
@@ -1352,7 +1542,7 @@ int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_s
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
-    rc = issue_on_entry(S, e, offset, d_scalars, n, window_begin, window_end, st);
+    rc = issue_on_entry(t, e, offset, d_scalars, n, window_begin, window_end, st);
     if (rc == BBGPU_ERR_ARG) set_error("bad window range [%d, %d)", window_begin, window_end);
     if (rc) return rc;
     if (t < 2) g_ctx.next_slot = t ^ 1;
@@ -1363,7 +1553,7 @@ int bbgpu_srs_has_window_tables(int srs_handle)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (srs_handle < 0 || srs_handle >= (int)g_ctx.srs.size() || !g_ctx.srs[srs_handle].live) return BBGPU_ERR_ARG;
-    return g_ctx.srs[srs_handle].d_tab ? 1 : 0;
+    return g_ctx.srs[srs_handle].has_tab() ? 1 : 0;
 }
 
 int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, uint64_t row_begin, uint64_t row_end,
@@ -1381,8 +1571,9 @@ int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t
         set_error("MSM range [%zu, %zu) outside the registered table of %zu points", offset, offset + n, e.n);
         return BBGPU_ERR_ARG;
     }
-    if (!e.d_tab) {
-        set_error("row-range shares need the pre-shifted window tables (one shared bucket set): this table has none");
+    if (e.segs.size() != 1) {
+        set_error(e.has_tab() ? "row-range shares need ONE table segment: this SRS of %zu points keeps %zu (split it by point range instead)"
+                              : "row-range shares need the pre-shifted window tables (one shared bucket set): this table has none", e.n, e.segs.size());
         return BBGPU_ERR_STATE;
     }
     const int t = pick_slot();
@@ -1391,7 +1582,10 @@ int bbgpu_msm_g1_device_rows_async(int srs_handle, size_t offset, const uint64_t
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
     if (n && row_end > row_begin && !windows_resident(e, (int)(row_begin / n), (int)((row_end + n - 1) / n))) return BBGPU_ERR_STATE;
-    rc = msm_issue_rows(S, e.d_srs + offset * 16, e.d_tab + offset * 16, e.n, e.tab_c, d_scalars, n, row_begin, row_end, st, g_ctx.timing);
+    S.helper = -1;
+    S.append = false;
+    S.throughput = others_pending(&S);
+    rc = msm_issue_rows(S, e.d_srs + offset * 16, e.segs[0].d_tab + offset * 16, e.n, e.tab_c, d_scalars, n, row_begin, row_end, st, g_ctx.timing);
     if (rc == BBGPU_ERR_ARG) set_error("bad row range [%llu, %llu) of %d x %zu", (unsigned long long)row_begin, (unsigned long long)row_end, e.tab_W, n);
     if (rc) return rc;
     if (t < 2) g_ctx.next_slot = t ^ 1;
@@ -1412,8 +1606,9 @@ int bbgpu_msm_g1_device_buckets_async(int srs_handle, size_t offset, const uint6
         set_error("MSM range [%zu, %zu) outside the registered table of %zu points", offset, offset + n, e.n);
         return BBGPU_ERR_ARG;
     }
-    if (!e.d_tab) {
-        set_error("bucket-range shares need the pre-shifted window tables (one shared bucket set): this table has none");
+    if (e.segs.size() != 1) {
+        set_error(e.has_tab() ? "bucket-range shares need ONE table segment: this SRS of %zu points keeps %zu (split it by point range instead)"
+                              : "bucket-range shares need the pre-shifted window tables (one shared bucket set): this table has none", e.n, e.segs.size());
         return BBGPU_ERR_STATE;
     }
     const int t = pick_slot();
@@ -1426,7 +1621,10 @@ int bbgpu_msm_g1_device_buckets_async(int srs_handle, size_t offset, const uint6
         set_error("bad bucket share %d of %d", share, share_count);
         return BBGPU_ERR_ARG;
     }
-    rc = msm_issue_buckets(S, e.d_srs + offset * 16, e.d_tab + offset * 16, e.n, e.tab_c, d_scalars, n, (uint32_t)share, (uint32_t)share_count, st, g_ctx.timing);
+    S.helper = -1;
+    S.append = false;
+    S.throughput = others_pending(&S);
+    rc = msm_issue_buckets(S, e.d_srs + offset * 16, e.segs[0].d_tab + offset * 16, e.n, e.tab_c, d_scalars, n, (uint32_t)share, (uint32_t)share_count, st, g_ctx.timing);
     if (rc == BBGPU_ERR_ARG) set_error("bad bucket share %d of %d (at most one share per row of the bucket matrix)", share, share_count);
     if (rc) return rc;
     if (t < 2) g_ctx.next_slot = t ^ 1;
@@ -1447,8 +1645,8 @@ int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_
         set_error("bad batch: jobs %d, range [%zu, %zu) of %zu points", jobs, offset, offset + n, e.n);
         return BBGPU_ERR_ARG;
     }
-    if (!e.d_tab && jobs > 1) {
-        set_error("batched MSM needs an SRS registered with window tables (bbgpu_set_precompute, 1024 <= n <= 2^20)");
+    if ((!e.has_tab() && jobs > 1) || jobs > MSM_MAX_JOBS) {
+        set_error("batched MSM: 1..%d jobs over an SRS registered with window tables (bbgpu_set_precompute, n >= 1024)", MSM_MAX_JOBS);
         return BBGPU_ERR_ARG;
     }
     const int t = pick_slot();
@@ -1456,9 +1654,7 @@ int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_
     MsmSlot& S = g_ctx.slot[t];
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : S.stream;
-    if (!windows_resident(e, 0, entry_windows(e, n))) return BBGPU_ERR_STATE;
-    rc = msm_issue_batch(S, e.d_srs + offset * 16, e.d_tab ? e.d_tab + offset * 16 : nullptr, e.n, e.tab_c, d_scalars, jobs, n, 0, entry_windows(e, n), st,
-                         g_ctx.timing);
+    rc = issue_ticket(t, e, offset, d_scalars, jobs, n, 0, entry_windows(e, n), st);
     if (rc) return rc;
     if (t < 2) g_ctx.next_slot = t ^ 1;
     return t;
@@ -1467,14 +1663,13 @@ int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_
 int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending || !out) {
+    if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending || g_ctx.slot[ticket].is_helper || !out) {
         set_error("no MSM batch in flight for ticket %d", ticket);
         return BBGPU_ERR_ARG;
     }
-    MsmSlot& S = g_ctx.slot[ticket];
-    host::Xyzz res[4];
-    const uint32_t jobs = S.jobs;
-    int rc = msm_finish_batch(S, res, &g_ctx.last);
+    host::Xyzz res[MSM_MAX_JOBS];
+    const uint32_t jobs = g_ctx.slot[ticket].jobs;
+    int rc = finish_ticket(ticket, res, &g_ctx.last);
     if (rc) return rc;
     host::g1_batch_to_normalised(res, jobs, out); // one inversion for the whole batch
     return BBGPU_OK;
@@ -1483,12 +1678,12 @@ int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out)
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12])
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending) {
+    if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending || g_ctx.slot[ticket].is_helper || g_ctx.slot[ticket].jobs != 1) {
         set_error("no MSM in flight for ticket %d", ticket);
         return BBGPU_ERR_ARG;
     }
     host::Xyzz res;
-    int rc = msm_finish(g_ctx.slot[ticket], &res, &g_ctx.last);
+    int rc = finish_ticket(ticket, &res, &g_ctx.last);
     if (rc) return rc;
     host::g1_to_normalised(res, out);
     return BBGPU_OK;

@@ -51,7 +51,6 @@ constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
 constexpr int MSM_MAX_C = 16;    // largest window without tables (one bucket set per window); digits stored as int16
 // (with tables, one shared bucket set: up to 17-bit windows -> 15 of them at 2^20, digits stored as uint16 magnitude + sign bit; capi.hip picks the width)
 constexpr int MSM_THREADS = 256;
-constexpr int MSM_MAX_JOBS = 4;  // MSMs over the same points issued as one batch (one bucket set each)
 
 __device__ __forceinline__ void ld8(const uint32_t* p, uint32_t (&w)[8])
 {
@@ -1790,12 +1789,26 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
                     size_t n, int wb, int we, hipStream_t st, int want_timing, uint32_t row_i0, uint32_t row_i1, uint32_t brow0, uint32_t brow1)
 {
     MsmWorkspace& ws = S.ws;
-    S.jobs = (uint32_t)jobs;
-    S.n = n;
-    S.pending = false;
-    S.timed = false;
-    if (n == 0) { S.trivial = true; S.pending = true; return BBGPU_OK; }
-    S.trivial = false;
+    // a further piece of the MSM already issued on this slot (same jobs, same stream: stream order hands the workspace on), or a new MSM
+    const bool append = S.append && S.pending && S.npieces > 0;
+    S.append = false;
+    if (append && (S.jobs != (uint32_t)jobs || S.npieces >= MSM_MAX_PIECES)) {
+        set_error("internal: MSM piece %d does not continue the MSM on this slot", S.npieces);
+        return BBGPU_ERR_STATE;
+    }
+    if (!append) {
+        S.jobs = (uint32_t)jobs;
+        S.n = n;
+        S.pending = false;
+        S.timed = false;
+        S.npieces = 0;
+    } else {
+        S.n += n;
+    }
+    MsmPiece& PC = S.piece[S.npieces];
+    PC = MsmPiece{};
+    PC.hout_group = S.npieces ? S.piece[S.npieces - 1].hout_group + S.piece[S.npieces - 1].nw : 0u;
+    if (n == 0) { PC.trivial = true; S.npieces++; S.pending = true; return BBGPU_OK; }
     if (n > ((size_t)1 << 24)) { // sort entries carry a 24-bit point index
         set_error("MSM of %zu points: at most 2^24 points per call", n);
         return BBGPU_ERR_SIZE;
@@ -1844,10 +1857,15 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     const uint32_t slice_len = (uint32_t)((n + slices - 1) / slices);
     const uint32_t idx_stride = table ? (uint32_t)tab_stride : 0u;
     const uint32_t* points = table ? d_tab : d_srs;
-    S.c = P.c; S.nw = G; S.wb = table ? 0u : (uint32_t)wb; S.hbits = P.hbits; S.lbits = P.lbits;
+    PC.c = P.c; PC.nw = G; PC.wb = table ? 0u : (uint32_t)wb; PC.hbits = P.hbits; PC.lbits = P.lbits;
+    if (PC.hout_group + G > MSM_HOUT_GROUPS) {
+        set_error("MSM in %d pieces of %u bucket sets: the result array holds %u", S.npieces + 1, G, MSM_HOUT_GROUPS);
+        return BBGPU_ERR_SIZE;
+    }
+    // (a later piece is never larger than the first: the workspace is not reallocated under a piece still running on the stream)
     int rc = ws.ensure(MsmWorkspace::bytes_needed(n, c, (int)nw));
     if (rc) return rc;
-    if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, 64 * 64 * 128));
+    if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, (size_t)MSM_HOUT_GROUPS * 64 * 128));
     if (!S.done) HIPCHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
 
     const MsmCarve LY = carve(P, n, nw);
@@ -2001,7 +2019,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         // row + column sums in one launch (one workgroup tree per row / column), then Z and the bit-sliced sums in a second
         uint32_t* Rr = scratch;
         uint32_t* Cc = scratch + (size_t)G * H * 32;
-        uint32_t* dest = fold ? (uint32_t*)ws.h_out : texp; // pinned host memory is device-accessible under the same pointer
+        uint32_t* const hout = (uint32_t*)ws.h_out + (size_t)PC.hout_group * 64 * 32; // this piece's groups of the pinned result array
+        uint32_t* dest = fold ? hout : texp; // pinned host memory is device-accessible under the same pointer
         const uint32_t zero_words = G * 64 * 32;
         static const bool two_step_env = [] { const char* e = getenv("BBGPU_ROWCOL_TWO_STEP"); return !e || atoi(e) != 0; }(); // 0: the one-launch quad form for every size
         if (quad_tail && two_step_env && !bshare && rowcol_two_step(P) && (tp || jobs > 1)) { // alone, the one-launch form is ~20 us shorter
@@ -2019,27 +2038,28 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         else msm_final_kernel<<<dim3(1 + P.hbits + P.lbits, G), std::max(H, L), 0, st>>>(Rr, Cc, dest, P.hbits, P.lbits);
         if (tm) HIPCHK(hipEventRecord(ev[6], st));
     }
-    if (!fold) HIPCHK(hipMemcpyAsync(ws.h_out, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(S.done, st));
+    if (!fold) HIPCHK(hipMemcpyAsync((uint32_t*)ws.h_out + (size_t)PC.hout_group * 64 * 32, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(S.done, st)); // re-recorded by every piece: the event of the last one covers them all (one stream)
     HIPCHK(hipGetLastError());
+    S.npieces++;
     S.pending = true;
     return BBGPU_OK;
 }
 
 // Waits for an issued MSM and finishes it on the host:
 //   S_w = Z + sum_k 2^k TC_k + 2^l sum_k 2^k TR_k ;  result = sum_w 2^(c (wb + w)) S_w   (Horner from the top)
-static host::Xyzz group_sum(const MsmSlot& S, uint32_t w)
+static host::Xyzz group_sum(const MsmSlot& S, const MsmPiece& PC, uint32_t w)
 {
     auto pt = [&](uint32_t slot) {
         host::Xyzz q;
-        memcpy(&q, (const uint8_t*)S.ws.h_out + ((size_t)w * 64 + slot) * 128, 128);
+        memcpy(&q, (const uint8_t*)S.ws.h_out + ((size_t)(PC.hout_group + w) * 64 + slot) * 128, 128);
         return q;
     };
     host::Xyzz rs = host::g1_infinity();
-    for (int k = (int)S.hbits - 1; k >= 0; --k) rs = host::g1_add(host::g1_dbl(rs), pt(1 + k));
-    for (uint32_t k = 0; k < S.lbits; k++) rs = host::g1_dbl(rs);
+    for (int k = (int)PC.hbits - 1; k >= 0; --k) rs = host::g1_add(host::g1_dbl(rs), pt(1 + k));
+    for (uint32_t k = 0; k < PC.lbits; k++) rs = host::g1_dbl(rs);
     host::Xyzz cs = host::g1_infinity();
-    for (int k = (int)S.lbits - 1; k >= 0; --k) cs = host::g1_add(host::g1_dbl(cs), pt(32 + k));
+    for (int k = (int)PC.lbits - 1; k >= 0; --k) cs = host::g1_add(host::g1_dbl(cs), pt(32 + k));
     return host::g1_add(host::g1_add(rs, cs), pt(0));
 }
 static int finish_timing(MsmSlot& S, MsmTiming* timing)
@@ -2075,15 +2095,23 @@ int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing)
     if (!S.pending) return BBGPU_ERR_STATE;
     if (S.jobs > 1) return BBGPU_ERR_STATE; // a batch is collected with msm_finish_batch
     S.pending = false;
-    if (S.trivial) return BBGPU_OK;
-    HIPCHK(hipEventSynchronize(S.done));
-    host::Xyzz acc = host::g1_infinity();
-    for (int w = (int)S.nw - 1; w >= 0; --w) {
-        for (uint32_t k = 0; k < S.c; k++) acc = host::g1_dbl(acc);
-        acc = host::g1_add(acc, group_sum(S, (uint32_t)w));
+    bool waited = false;
+    host::Xyzz total = host::g1_infinity();
+    for (int pi = 0; pi < S.npieces; pi++) {
+        const MsmPiece& PC = S.piece[pi];
+        if (PC.trivial) continue;
+        if (!waited) HIPCHK(hipEventSynchronize(S.done));
+        waited = true;
+        host::Xyzz acc = host::g1_infinity();
+        for (int w = (int)PC.nw - 1; w >= 0; --w) {
+            for (uint32_t k = 0; k < PC.c; k++) acc = host::g1_dbl(acc);
+            acc = host::g1_add(acc, group_sum(S, PC, (uint32_t)w));
+        }
+        for (uint32_t k = 0; k < PC.c * PC.wb; k++) acc = host::g1_dbl(acc);
+        total = host::g1_add(total, acc);
     }
-    for (uint32_t k = 0; k < S.c * S.wb; k++) acc = host::g1_dbl(acc);
-    *result = acc;
+    *result = total;
+    if (!waited) return BBGPU_OK;
     return finish_timing(S, timing);
 }
 // one result per job of a batch (table mode: every job is one bucket set, no positional doublings)
@@ -2093,9 +2121,15 @@ int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing)
     if (!S.pending) return BBGPU_ERR_STATE;
     S.pending = false;
     for (uint32_t j = 0; j < S.jobs; j++) results[j] = host::g1_infinity();
-    if (S.trivial) return BBGPU_OK;
-    HIPCHK(hipEventSynchronize(S.done));
-    for (uint32_t j = 0; j < S.jobs; j++) results[j] = group_sum(S, j);
+    bool waited = false;
+    for (int pi = 0; pi < S.npieces; pi++) {
+        const MsmPiece& PC = S.piece[pi];
+        if (PC.trivial) continue;
+        if (!waited) HIPCHK(hipEventSynchronize(S.done));
+        waited = true;
+        for (uint32_t j = 0; j < S.jobs; j++) results[j] = host::g1_add(results[j], group_sum(S, PC, j));
+    }
+    if (!waited) return BBGPU_OK;
     return finish_timing(S, timing);
 }
 
@@ -2111,6 +2145,9 @@ void MsmSlot::release()
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
     pending = false;
+    npieces = 0;
+    helper = -1;
+    is_helper = append = false;
 }
 
 // ---- SRS management --------------------------------------------------------------------------------------------------

@@ -285,7 +285,7 @@ int bbgpu_plonk_challenges_from_proof(const uint64_t proof[BBGPU_PLONK_PROOF_WOR
  * The reference API has no error channel (assert.hpp:13-23; batched_scalar_multiplications prints and returns, scalar_multiplication.cpp:680-684),
  * so a GPU call that fails at run time -- no device, an allocation refused on a shared GPU, a launch failure -- must not stop the prover:
  * shim/bb_shim.cpp logs the library's error once and computes the same result with these entries (csrc/host_fallback.hpp: textbook bucket
- * method / radix-2 transform / O(n) loops on the library's own host field code, a few std::threads; never oracle/).  They make no HIP call,
+ * method / radix-2 transform / O(n) loops on the library's own host field code, a few host threads; never oracle/).  They make no HIP call,
  * take no lock and keep no state (re-entrant), accept what the GPU entries accept (any representative below 2^256) and return the same bytes
  * (canonical; MSM results normalised).  The GPU entries above never call them. */
 int bbgpu_host_msm_g1(const uint64_t* scalars, const uint64_t* points, size_t n, int plain_table /* 0: 2n-entry endo table, 1: n-entry table */, uint64_t out[12]);

@@ -237,3 +237,52 @@ def test_partial_sum_exchange_over_rccl_world_size_1(gpu, oracle, tables):
         gpu.srs_release(h)
     finally:
         dist.destroy_process_group()
+
+
+def test_concurrent_callers_of_the_drop_in_entries(gpu, oracle, golden):
+    """The reference enters pippenger() from inside `#pragma omp parallel for` (scalar_multiplication.cpp:731-738) and has no error channel: eight
+    host threads call bbgpu_msm_g1 / bbgpu_ntt on their own buffers at once while the main thread HOLDS an asynchronous ticket (and one of them
+    keeps issuing and collecting tickets of its own).  Calls are serialised by the library mutex and take whatever MSM slots are free -- none may
+    fail with BBGPU_ERR_STATE, every result equals the oracle's."""
+    import threading
+    import torch
+    g = golden("msm.json")
+    n_big = 65536
+    x = limbs(g["srs_secret_mont"])
+    h, table = gpu.srs_generate(x, n_big, True)
+    scalars = oracle.random_scalars(SCALAR_SEED, n_big)
+    d_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
+    want_big = [c for c in g["cases"] if c["n"] == n_big and "x" in c][0]
+    sizes = [4096, 1000, 10000, 65536, 100, 4096, 16, 65536]
+    want = {n: [c for c in g["cases"] if c["n"] == n and "x" in c][0] for n in set(sizes)}
+    ntt_in = {k: noncanonical(oracle.random_scalars(NTT_SEED + 300 + k, 1 << (8 + k)), FR_MODULUS) for k in range(4)}
+    ntt_want = {k: oracle.ntt(v, "coset_fft") for k, v in ntt_in.items()}
+    held = gpu.msm_device_async(h, d_sc.data_ptr(), n_big)  # stays in flight for the whole test
+    errors, rounds = [], 6
+
+    def worker(i):
+        try:
+            n = sizes[i]
+            sc = aligned_copy(scalars[:n])
+            for r in range(rounds):
+                out = gpu.pippenger(sc, table, n)
+                assert np.array_equal(out[0:4], limbs(want[n]["x"])) and np.array_equal(out[4:8], limbs(want[n]["y"])), ("msm", i, r)
+                k = (i + r) % 4
+                got = gpu.coset_fft(ntt_in[k].copy())
+                assert np.array_equal(got, ntt_want[k]), ("ntt", i, r)
+                if i == 0:  # tickets of its own beside the held one
+                    t = gpu.msm_device_async(h, d_sc.data_ptr(), 4096)
+                    o2 = gpu.msm_wait(t)
+                    assert np.array_equal(o2[0:4], limbs(want[4096]["x"])), ("ticket", r)
+        except BaseException as exc:  # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    out = gpu.msm_wait(held)
+    assert not errors, errors
+    assert np.array_equal(out[0:4], limbs(want_big["x"])) and np.array_equal(out[4:8], limbs(want_big["y"]))
+    gpu.srs_release(h)

@@ -602,6 +602,49 @@ def test_msm_around_the_table_mode_switch(gpu, oracle, golden):
         gpu.srs_release(h)
 
 
+def test_msm_beyond_one_table_segment(gpu, oracle, golden):
+    """n > 2^20: the SRS keeps one window table per <= 2^20-point segment (capi.hip add_srs) and an MSM runs as point-range pieces -- dealt to the
+    ticket's slot and a helper slot, piece sums added on the host -- instead of falling back to per-window bucket sets.  Points the REFERENCE
+    computed for prefixes of a 2^21-point SRS (tests/golden/msm_r4.json, tools/gen_golden_r4.py): 2^19 + 3 (ragged, two ranges at the host entry,
+    ADVICE r3), 2^20 + 8 and 2^21 (two segments), and scalars[0:n] against points [5, 5 + n) (a sub-slice across the segment boundary), through
+    the device entry, the host-pointer entries, the batched entry and two compound tickets in flight."""
+    import torch
+    g = golden("msm_r4.json")
+    x = limbs(g["srs_secret_mont"])
+    N = 1 << 21
+    h, table = gpu.srs_generate(x, N, True)
+    assert sha(table[0::2]) == g["srs_digest_2097152"]
+    scalars = oracle.random_scalars(SCALAR_SEED, N)
+    d_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
+    for case in g["prefixes"]:
+        n = case["n"]
+        _check(gpu.msm_device(h, d_sc.data_ptr(), n), case)
+        _check(gpu.pippenger(aligned_copy(scalars[:n]), table, n), case)  # host pointers: served from the resident copy of `table`
+    n = g["prefixes"][0]["n"]  # 2^19 + 3 on the PLAIN n-entry table (pippenger_low_memory): used once, its own upload, two ragged ranges
+    _check(gpu.pippenger_low_memory(aligned_copy(scalars[:n]), aligned_copy(table[0:2 * n:2]), n), g["prefixes"][0])
+    sl = g["slice"]
+    _check(gpu.msm_device(h, d_sc.data_ptr(), sl["n"], offset=sl["offset"]), sl)
+    _check(gpu.pippenger(aligned_copy(scalars[:sl["n"]]), table[2 * sl["offset"]:], sl["n"]), sl)
+    full = g["prefixes"][-1]
+    # two tickets of 2^21 points in flight (each in two pieces; the first takes a helper slot, the second whatever is left)
+    t1, t2 = gpu.msm_device_async(h, d_sc.data_ptr(), N), gpu.msm_device_async(h, d_sc.data_ptr(), N)
+    _check(gpu.msm_wait(t2), full)
+    _check(gpu.msm_wait(t1), full)
+    if gpu.srs_has_window_tables(h):
+        assert gpu.srs_num_windows(h, N) == 15
+        # the batched entry over two segments: three jobs in one pass per piece
+        rev = torch.from_numpy(np.ascontiguousarray(scalars[::-1]).view(np.int64)).cuda()
+        got = gpu.msm_batch_wait(gpu.msm_device_batch_async(h, [d_sc.data_ptr(), rev.data_ptr(), d_sc.data_ptr()], N))
+        _check(got[0], full)
+        _check(got[2], full)
+        assert np.array_equal(got[1], gpu.msm_device(h, rev.data_ptr(), N))
+        # row / bucket shares are defined on ONE table segment: refused here (a larger MSM is split by point range)
+        from barretenberg_amd import BbGpuError
+        with pytest.raises(BbGpuError, match="ONE table segment"):
+            gpu.msm_device_rows_async(h, d_sc.data_ptr(), N, 0, N)
+    gpu.srs_release(h)
+
+
 def test_msm_skewed_scalars_full_size(gpu, oracle, golden):
     """the skewed scalar sets (every scalar equal, {0, 1, -1}, values below 200: bench.skewed_scalars) at the FULL 2^20 size -- the
     heavy-bucket merge path at the size the headline is quoted on -- against the reference's points for the same vectors"""
