@@ -51,8 +51,14 @@ C_ABI_SYMBOLS = [
     "bbgpu_plonk_prover_create", "bbgpu_plonk_prover_set_witness", "bbgpu_plonk_construct_proof", "bbgpu_plonk_preprocess", "bbgpu_plonk_last_challenges",
     "bbgpu_plonk_last_timing", "bbgpu_plonk_prover_destroy", "bbgpu_plonk_challenges_from_proof",
     "bbgpu_host_msm_g1", "bbgpu_host_ntt", "bbgpu_host_fr_evaluate", "bbgpu_host_kate_opening", "bbgpu_host_lagrange_l1_fft",
-    "bbgpu_host_divide_by_pseudo_vanishing",
+    "bbgpu_host_divide_by_pseudo_vanishing", "bbgpu_memory_stats",
 ]
+
+
+class MemoryInfo(C.Structure):
+    """bbgpu_memory_info (include/bbgpu.h)"""
+    _fields_ = [(k, C.c_uint64) for k in ("srs_points_bytes", "srs_table_bytes", "srs_auto_bytes", "srs_cache_cap_bytes", "ntt_table_bytes", "ntt_table_cap_bytes",
+                                          "ntt_table_sets", "msm_workspace_bytes", "staging_bytes", "pinned_host_bytes")]
 
 
 class BbGpuError(RuntimeError):
@@ -233,6 +239,12 @@ class BbGpu:
         a, b, c = C.c_int(0), C.c_int(0), C.c_uint64(0)
         self._chk(self.lib.bbgpu_srs_cache_stats(C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def memory_stats(self):
+        """device / pinned bytes the library holds for the life of the process, as a dict (bbgpu_memory_stats)"""
+        info = MemoryInfo()
+        self._chk(self.lib.bbgpu_memory_stats(C.byref(info)))
+        return {k: int(getattr(info, k)) for k, _ in MemoryInfo._fields_}
 
     def srs_release(self, handle):
         self._chk(self.lib.bbgpu_srs_release(handle))

@@ -17,6 +17,7 @@ int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, con
 int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256,
                      hipStream_t st);
 void ntt_release_tables();
+size_t ntt_table_bytes(size_t* cap_out, int* sets_out); // device bytes the cached twiddle / twist tables hold now, their budget, how many domain sizes
 
 // msm.hip
 namespace host { struct Xyzz; }

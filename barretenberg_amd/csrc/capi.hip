@@ -832,6 +832,34 @@ void bbgpu_shutdown(void)
     g_ctx.ready = false;
 }
 
+int bbgpu_memory_stats(bbgpu_memory_info* out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!out) return BBGPU_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    for (const auto& e : g_ctx.srs) {
+        if (!e.live) continue;
+        const uint64_t pts = (uint64_t)e.n * 64, tab = e.bytes > pts ? e.bytes - pts : 0;
+        out->srs_points_bytes += pts;
+        out->srs_table_bytes += tab;
+        if (e.auto_registered) out->srs_auto_bytes += e.bytes;
+    }
+    out->srs_cache_cap_bytes = g_ctx.srs_cache_cap;
+    size_t cap = 0;
+    int sets = 0;
+    out->ntt_table_bytes = ntt_table_bytes(&cap, &sets);
+    out->ntt_table_cap_bytes = cap;
+    out->ntt_table_sets = (uint64_t)sets;
+    for (const auto& sl : g_ctx.slot) {
+        out->msm_workspace_bytes += sl.ws.cap;
+        if (sl.ws.h_out) out->pinned_host_bytes += (uint64_t)MSM_HOUT_GROUPS * 64 * 128;
+    }
+    out->staging_bytes = g_ctx.stage_cap + g_ctx.stage2_cap + g_ctx.scratch_cap + g_ctx.poly_tmp_cap + g_ctx.poly_scratch.cap;
+    for (int k = 0; k < 2; k++)
+        if (g_ctx.h_stage[k]) out->pinned_host_bytes += Context::HOST_CHUNK;
+    return BBGPU_OK;
+}
+
 void bbgpu_set_timing(int enabled)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -1660,8 +1688,28 @@ int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_
     return t;
 }
 
+// The blocking part of a wait runs WITHOUT the library mutex: the events of the ticket's slot (and of its helper) are picked up under the lock,
+// waited for outside it, and only the host finish -- which then finds them complete -- takes the lock again.  A thread that collects tickets
+// therefore never stops another one from issuing (a rank of a multi-GPU split issues from one thread and collects / exchanges on another,
+// barretenberg_amd/sharding.py; the reference calls pippenger() from an OpenMP region).  The caller's part of the contract is the usual one: a
+// ticket is waited for once, by one thread.
+static void wait_ticket_events_unlocked(int ticket)
+{
+    hipEvent_t ev[2] = { nullptr, nullptr };
+    {
+        std::lock_guard<std::recursive_mutex> lk(g_mu);
+        if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending || g_ctx.slot[ticket].is_helper) return; // the locked part reports it
+        const MsmSlot& S = g_ctx.slot[ticket];
+        ev[0] = S.done;
+        if (S.helper >= 0) ev[1] = g_ctx.slot[S.helper].done;
+    }
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventSynchronize(e); // errors surface in the locked finish, which synchronises again
+}
+
 int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out)
 {
+    wait_ticket_events_unlocked(ticket);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending || g_ctx.slot[ticket].is_helper || !out) {
         set_error("no MSM batch in flight for ticket %d", ticket);
@@ -1677,6 +1725,7 @@ int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out)
 
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12])
 {
+    wait_ticket_events_unlocked(ticket);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (ticket < 0 || ticket >= Context::NSLOT || !g_ctx.slot[ticket].pending || g_ctx.slot[ticket].is_helper || g_ctx.slot[ticket].jobs != 1) {
         set_error("no MSM in flight for ticket %d", ticket);

@@ -603,14 +603,33 @@ struct DomainTables {
     uint32_t* scale_lo[2] = { nullptr, nullptr };                            // [0]: g^i, [1]: g^-i * n^-1
     uint32_t* scale_hi[2] = { nullptr, nullptr };
     Limbs9 n_inv;                                                            // Montgomery-261
+    size_t bytes = 0;       // device bytes of this table set
+    uint64_t last_use = 0;  // LRU clock
 };
 
 std::mutex g_mu;
 std::unordered_map<int, DomainTables*> g_domains; // keyed by device * 64 + log2n
+// The table sets are built on first use of a domain size and kept -- up to a byte budget (BBGPU_NTT_TABLE_BYTES, default 8 GiB: a 2^20 domain holds
+// 128 MiB, a 2^22 one 512 MiB).  Beyond it the least recently used sets are dropped and rebuilt when their size comes back (a rebuild is a few
+// launches: 2^20 ~0.3 ms, 2^22 ~1 ms).  A set the running call has already fetched (the two domains of a three-pass transform) is never the victim.
+size_t g_table_bytes = 0;
+uint64_t g_clock = 0;
+size_t table_cap() // read when a new table set is built (rare), so a long-lived process can be re-budgeted
+{
+    const char* e = getenv("BBGPU_NTT_TABLE_BYTES");
+    return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)8 << 30;
+}
+DomainTables* g_building = nullptr; // the set whose allocations are being accounted (build_domain runs under g_mu)
+hipError_t table_malloc(void** out, size_t bytes)
+{
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess && g_building) g_building->bytes += bytes;
+    return e;
+}
 
 hipError_t pow_table(uint32_t** out, uint32_t count, const H& base, const H& factor, hipStream_t st)
 {
-    hipError_t e = hipMalloc((void**)out, (size_t)count * TW_WORDS * 4);
+    hipError_t e = table_malloc((void**)out, (size_t)count * TW_WORDS * 4);
     if (e != hipSuccess) return e;
     ntt_pow_table_kernel<<<(count + 127) / 128, 128, 0, st>>>(*out, count, to_limbs(base), to_limbs(factor));
     return hipGetLastError();
@@ -666,7 +685,7 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
         if ((e = pow_table(&D->twist_hi[inv], 1u << (log2n - D->lo_bits), h_pow2k(w, D->lo_bits), one, st)) != hipSuccess) return e;
         if (full_twist_enabled() && !three && D->log_s2 > 0 && log2n <= NTT_FULL_TWIST_MAX_LOG2N) {
             const uint32_t n = 1u << log2n;
-            if ((e = hipMalloc((void**)&D->twist_full[inv], (size_t)n * 32)) != hipSuccess) return e;
+            if ((e = table_malloc((void**)&D->twist_full[inv], (size_t)n * 32)) != hipSuccess) return e;
             ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->twist_full[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n, nullptr, 0u);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
@@ -687,10 +706,12 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
             if ((e = pow_table(&D->coset_row[0], 1u << D->log_s1, h_pow2k(g, D->log_s2), one, st)) != hipSuccess) return e;   // (g^n2)^j1
             if ((e = pow_table(&D->coset_row[1], 1u << D->log_s2, h_pow2k(gi, D->log_s1), one, st)) != hipSuccess) return e;  // (g^-n1)^k2
             uint32_t *gb = nullptr, *gk = nullptr; // g^b, b < n2 and g^-k n^-1, k < n1: folded into the coset twist tables, then dropped
+            const size_t before_tmp = D->bytes;
             if ((e = pow_table(&gb, 1u << D->log_s2, g, one, st)) != hipSuccess) return e;
             if ((e = pow_table(&gk, 1u << D->log_s1, gi, ninv, st)) != hipSuccess) { (void)hipFree(gb); return e; }
+            const size_t tmp_bytes = D->bytes - before_tmp;
             for (int inv = 0; inv < 2 && e == hipSuccess; inv++) {
-                if ((e = hipMalloc((void**)&D->coset_twist[inv], (size_t)n * 32)) != hipSuccess) break;
+                if ((e = table_malloc((void**)&D->coset_twist[inv], (size_t)n * 32)) != hipSuccess) break;
                 ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->coset_twist[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n,
                                                                        inv ? gk : gb, (uint32_t)inv);
                 e = hipGetLastError();
@@ -698,6 +719,7 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
             (void)hipStreamSynchronize(st);
             (void)hipFree(gb);
             (void)hipFree(gk);
+            D->bytes -= tmp_bytes;
             if (e != hipSuccess) return e;
         }
     }
@@ -722,27 +744,48 @@ void free_domain(DomainTables* D)
     delete D;
 }
 
-hipError_t get_domain(int log2n, hipStream_t st, DomainTables** out)
+// keep: a table set the running call fetched earlier (never evicted by this fetch), or null
+hipError_t get_domain(int log2n, hipStream_t st, DomainTables** out, const DomainTables* keep = nullptr)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_domains.find(dev * 64 + log2n);
     if (it != g_domains.end()) {
+        it->second->last_use = ++g_clock;
         *out = it->second;
         return hipSuccess;
     }
     DomainTables* D = new DomainTables();
+    g_building = D;
     hipError_t e = build_domain(D, log2n, st);
+    g_building = nullptr;
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(st); // kernels of the tables built so far
         free_domain(D);                 // including the partially built set
         return e;
     }
+    D->last_use = ++g_clock;
+    g_table_bytes += D->bytes;
     g_domains[dev * 64 + log2n] = D;
+    // over the budget: drop the least recently used sets (not this one, not `keep`).  Transforms that still use a victim may be in flight on any
+    // stream: drain the device first (rare path: a process that walks through more domain sizes than the budget holds)
+    bool drained = false;
+    while (g_table_bytes > table_cap()) {
+        auto victim = g_domains.end();
+        for (auto jt = g_domains.begin(); jt != g_domains.end(); ++jt)
+            if (jt->second != D && jt->second != keep && (victim == g_domains.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+        if (victim == g_domains.end()) break; // the sets of the running call alone exceed the budget: they stay
+        if (!drained) (void)hipDeviceSynchronize();
+        drained = true;
+        g_table_bytes -= victim->second->bytes;
+        free_domain(victim->second);
+        g_domains.erase(victim);
+    }
     *out = D;
     return hipSuccess;
 }
+
 
 bool fused_enabled()
 {
@@ -816,7 +859,7 @@ static int ntt_device_three_pass(uint64_t* d_coeffs, uint64_t* d_scratch, int lo
 {
     const int lm = 2 * (log2n / 3), l1 = log2n - lm; // row transforms split evenly; every sub-transform <= 2^10
     DomainTables *D, *Dm;
-    if (get_domain(log2n, st, &D) != hipSuccess || get_domain(lm, st, &Dm) != hipSuccess) return BBGPU_ERR_HIP;
+    if (get_domain(log2n, st, &D) != hipSuccess || get_domain(lm, st, &Dm, D) != hipSuccess) return BBGPU_ERR_HIP;
     const bool inverse = (kind == BBGPU_IFFT || kind == BBGPU_COSET_IFFT || kind == BBGPU_IFFT_WITH_CONSTANT);
     const bool pre = (kind == BBGPU_COSET_FFT || kind == BBGPU_COSET_FFT_WITH_CONSTANT);
     const bool post_table = (kind == BBGPU_COSET_IFFT);
@@ -998,11 +1041,20 @@ int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_
     return BBGPU_OK;
 }
 
+size_t ntt_table_bytes(size_t* cap_out, int* sets_out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (cap_out) *cap_out = table_cap();
+    if (sets_out) *sets_out = (int)g_domains.size();
+    return g_table_bytes;
+}
+
 void ntt_release_tables()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& kv : g_domains) free_domain(kv.second);
     g_domains.clear();
+    g_table_bytes = 0;
 }
 
 } // namespace bbgpu

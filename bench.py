@@ -94,7 +94,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from barretenberg_amd import BbGpu  # noqa: E402
-from barretenberg_amd.sharding import PartialSumExchange, pipelined_steps  # noqa: E402
+from barretenberg_amd.sharding import PartialSumExchange, StepClock, pipelined_steps  # noqa: E402
 
 LOG2N = 20
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
@@ -152,6 +152,16 @@ def to_montgomery_on_device(G, raw, dev):
     G.mul_device(d_out.data_ptr(), d_raw.data_ptr(), d_rsq.data_ptr(), n)
     torch.cuda.synchronize()
     return d_out
+
+
+def lib_sha16():
+    """first 16 hex digits of the SHA-256 of the libbbgpu.so this process loaded (ties a bench line to a binary)"""
+    import hashlib
+    from barretenberg_amd.bbgpu import library_path
+    try:
+        return hashlib.sha256(open(library_path(), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def median_ms(fn, reps=10, warm=3):
@@ -338,7 +348,10 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive (host-pointer, PCIe) legs, the 2^22 transforms and config 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the partial-sum exchange (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo)")
-    ap.add_argument("--probe", action="store_true", help="no GPU work: form the process group of the N ranks, report who is there, exit (launch check)")
+    ap.add_argument("--probe", action="store_true", help="no MSM: form the process group of the N ranks over --backend (nccl = RCCL on the ranks' GPUs), one all-gather of 96 bytes, "
+                    "report who is there and on which devices, exit; non-zero with the backend's own error text when the group cannot be formed")
+    ap.add_argument("--exchange-group", type=int, default=0, help="N > 1: partial sums of this many MSMs per all-gather (0 = the pipeline depth)")
+    ap.add_argument("--issuer-thread", type=int, default=1, help="N > 1: 1 = the shares are issued by a helper thread while the main thread collects and exchanges")
     ap.add_argument("--no-window-split-leg", action="store_true", help="N > 1 with the default split: skip the extra timed leg that runs the same MSM split by window rows")
     ap.add_argument("--shard", default="points", choices=("points", "buckets", "rows", "windows"),
                     help="N > 1: how one MSM is split over the ranks (points: rank r holds points and scalars [n r / N, n (r + 1) / N) with all their digit windows -- "
@@ -358,31 +371,77 @@ def main():
         sys.exit(2)
     if args.same_device:
         local_rank = 0
-    if world > 1:
+    def device_identity(i):
+        """PCI address of cuda:i as (domain, bus, device), -1s when the build does not expose it"""
+        try:
+            p = torch.cuda.get_device_properties(i)
+            return [int(getattr(p, "pci_domain_id", -1)), int(getattr(p, "pci_bus_id", -1)), int(getattr(p, "pci_device_id", -1))]
+        except Exception:
+            return [-1, -1, -1]
+
+    def rccl_version():
+        try:
+            v = torch.cuda.nccl.version()
+            return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception:
+            return None
+
+    if world > 1 or args.probe:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl" and not args.probe:
-            have = torch.cuda.device_count()  # counting devices does not initialise the GPU
-            if have <= local_rank:
-                print("bench.py: rank %d needs cuda:%d, this node shows %d GPU(s)" % (rank, local_rank, have), file=sys.stderr)
-                sys.exit(3)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo" if args.probe else args.backend, rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        try:
+            if args.backend == "nccl":
+                have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+                if have <= local_rank:
+                    raise RuntimeError("rank %d needs cuda:%d, this node shows %d GPU(s)" % (rank, local_rank, have))
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
+        except Exception as exc:  # the backend's own words, and a non-zero exit: never a silent switch to another backend
+            print("bench.py: rank %d could not join the %s process group of %d: %s: %s" % (rank, args.backend, world, type(exc).__name__, exc), file=sys.stderr, flush=True)
+            sys.exit(3)
     if args.probe:
-        # who is there: every rank's (rank, pid, parent pid) through one all-gather of the group the timed run would use
-        mine = torch.tensor([rank, os.getpid(), os.getppid()], dtype=torch.int64)
-        seen = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
-        if world > 1:
-            dist.all_gather(seen, mine)
-        else:
-            seen = [mine]
+        # A two-second sanity line of the group the timed run would use, on the devices it would use: who is there (rank, pid, parent pid, PCI address
+        # of the rank's GPU) through ONE all-gather of 96 bytes per rank -- the size and shape of the partial-sum exchange -- over args.backend.
+        on_gpu = args.backend == "nccl"
+        pdev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+        mine = torch.tensor([rank, os.getpid(), os.getppid()] + (device_identity(local_rank) if on_gpu else [-1, -1, -1]) + [0] * 6, dtype=torch.int64, device=pdev)
+        seen = torch.zeros(world * 12, dtype=torch.int64, device=pdev)
+        def gather():
+            if on_gpu or hasattr(dist, "all_gather_into_tensor"):
+                try:
+                    dist.all_gather_into_tensor(seen, mine)
+                    return
+                except (RuntimeError, NotImplementedError):
+                    if on_gpu:
+                        raise
+            dist.all_gather(list(seen.view(world, 12).unbind(0)), mine)  # a CPU backend without the flat form
+
+        t0 = time.perf_counter()
+        try:
+            gather()
+            if on_gpu:
+                torch.cuda.synchronize()
+        except Exception as exc:
+            print("bench.py: rank %d: the 96-byte all-gather over %s failed: %s: %s" % (rank, args.backend, type(exc).__name__, exc), file=sys.stderr, flush=True)
+            sys.exit(4)
+        first_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gather()
+        if on_gpu:
+            torch.cuda.synchronize()
+        each_us = (time.perf_counter() - t0) / 20 * 1e6
+        seen = seen.cpu().view(world, 12)
         if rank == 0:
-            print(json.dumps({"probe": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            print(json.dumps({"probe": True, "n_gpus": world, "backend": args.backend, "rccl_ranks": dist.get_world_size(), "rccl_version": rccl_version() if on_gpu else None,
                               "ranks": [int(t[0]) for t in seen], "pids": [int(t[1]) for t in seen], "parent_pids": [int(t[2]) for t in seen],
+                              "devices": ["%04x:%02x:%02x" % (int(t[3]), int(t[4]), int(t[5])) if int(t[4]) >= 0 else None for t in seen],
+                              "all_gather_96B_first_ms": first_ms, "all_gather_96B_us": each_us,
                               "launcher_pid": int(os.environ.get("BBGPU_BENCH_LAUNCHER_PID", "0"))}), flush=True)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         fail = os.environ.get("BBGPU_BENCH_PROBE_FAIL_RANK")
         sys.exit(7 if fail is not None and int(fail) == rank else 0)
     torch.cuda.set_device(local_rank)
@@ -457,22 +516,29 @@ def main():
             part[7] = np.uint64(1 << 63)
         return part
 
-    exchange = PartialSumExchange(G, world, xdev) if world > 1 else None
     # shares in flight: two at N <= 2 (more changes nothing there: the step is the accumulation), four from N = 4 on, where a share is a chain of
     # short launches (tools/share_ab.py with GPU_MAX_HW_QUEUES=8, a middle 1/8 row share: 0.362 / 0.254 / 0.217 / 0.213 / 0.232 / 0.219 ms per step
     # with 1 / 2 / 3 / 4 / 6 / 8 in flight; 1/4: 0.589 / 0.372 / 0.350 / 0.348 / 0.351 / 0.359)
     depth = 4 if world >= 4 else 2
+    # the partial sums of the `depth` shares in flight travel in ONE all-gather, and the shares are issued by a helper thread: a rank's host
+    # thread paid 44 us issue + 15 us wait + 63 us exchange per step against a share of ~0.18 ms at N = 8 (profiles/r03_*_cost.txt)
+    exchange = PartialSumExchange(G, world, xdev, group=(args.exchange_group or depth)) if world > 1 else None
+    use_issuer = world > 1 and args.issuer_thread != 0
+    clock = StepClock()
 
     def run_steps(k):
         """k complete MSMs; step i+1 is enqueued before step i is collected (two-slot pipeline of the library), so the
         bucket-reduction tail + host finish of one step overlap the sort/accumulate of the next; with N > 1 the exchange of
         step i is in flight while step i+1 is collected (barretenberg_amd/sharding.py)"""
-        out = pipelined_steps(k, issue, collect, exchange, depth=depth)
+        out = pipelined_steps(k, issue, collect, exchange, depth=depth, clock=clock, issuer=use_issuer)
         return out[-1] if out else None
 
     def finish(ticket):
         part = collect(ticket)
-        return part if world == 1 else exchange.finish(exchange.start(part))
+        if world == 1:
+            return part
+        got = exchange.finish(exchange.start([part]))
+        return got[0] if isinstance(got, list) else got
 
     # The first ~50 ms of sustained work after idle run ~4 % slower than the steady state on this part (tools/step_gap.py: 1.33 ms for the
     # first 20-step batch, 1.27 ms for every later one, independent of inputs and instrumentation), so the pipeline is brought to its
@@ -485,11 +551,14 @@ def main():
     G.set_timing(2)
     stage_log.clear()
     barrier()
+    clock.__init__()
     t0 = time.perf_counter()
     res = run_steps(args.steps)
+    t_mine = time.perf_counter() - t0  # this rank's own wall time, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     G.set_timing(False)
+    host_us = clock.per_step_us()
     acc_pipe = np.mean(np.array(stage_log), axis=0) if stage_log else np.zeros(8)
     G.set_timing(1)
     stage_log.clear()
@@ -497,10 +566,27 @@ def main():
     barrier()
     G.set_timing(False)
     stage_pipe = np.mean(np.array(stage_log), axis=0) if stage_log else np.zeros(8)
+    per_rank = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # one gather AFTER the timed region: every rank's own step time, the host time its thread(s) spent per step in issue / wait / exchange, its
+        # GPU -- so that a disappointing curve can be read from the record instead of guessed at
+        mine = torch.tensor([t_mine / args.steps * 1e3] + [host_us[k] for k in StepClock.KEYS] + [float(v) for v in device_identity(local_rank)],
+                            dtype=torch.float64, device=xdev)
+        allr = torch.zeros(world * mine.numel(), dtype=torch.float64, device=xdev)
+        dist.all_gather_into_tensor(allr, mine) if exchange.flat else dist.all_gather(list(allr.view(world, -1).unbind(0)), mine)
+        allr = allr.cpu().view(world, -1).numpy()
+        per_rank = {"rank_ms_per_step": [float(v) for v in allr[:, 0]],
+                    "rank_host_us_per_step": {k: [float(v) for v in allr[:, 1 + i]] for i, k in enumerate(StepClock.KEYS)},
+                    "rank_skew_ms": float(allr[:, 0].max() - allr[:, 0].min()) * args.steps,
+                    "devices": ["%04x:%02x:%02x" % (int(r[5]), int(r[6]), int(r[7])) if r[6] >= 0 else None for r in allr],
+                    "rccl_version": rccl_version() if args.backend == "nccl" else None,
+                    "exchange_group": exchange.group, "issuer_thread": bool(use_issuer), "shares_in_flight": depth,
+                    "note": "rank_ms_per_step: each rank's own wall time over the timed steps / steps, before the closing barrier (ms_per_step is the MAX over ranks incl. the barrier); "
+                            "rank_host_us_per_step: host time per step inside issue() (helper thread when issuer_thread), wait = collect of a share, exchange_start / _finish "
+                            "(one all-gather per exchange_group steps); rank_skew_ms: (slowest - fastest rank) over the whole timed region"}
     msm_ms = dt / args.steps * 1e3
     # latency of one isolated MSM (no pipelining): median of 10 after 3
     msm_latency_ms, msm_latency_min = median_ms(lambda: finish(issue()), 10, 3)
@@ -528,7 +614,7 @@ def main():
             return G.msm_device_rows_async(srs_rows, d_scalars.data_ptr(), n, rr[0], rr[1]) if rr[1] > rr[0] else None
 
         def run_rows(k):
-            out = pipelined_steps(k, issue_rows, collect, exchange, depth=depth)
+            out = pipelined_steps(k, issue_rows, collect, exchange, depth=depth, issuer=use_issuer)
             return out[-1] if out else None
 
         run_rows(20 + args.warmup)
@@ -648,28 +734,30 @@ def main():
         b_msm, b_msm_min = median_ms(one_msm, 10, 3)
         assert np.array_equal(G.pippenger(hs[0], table, n), res), "host-pointer MSM differs from the resident one"
         b_bat, b_bat_min = median_ms(lambda: G.batched_scalar_multiplications([(table, h, n) for h in hs]), 10, 3)
-        host_co = ntt_in.copy()
+        # bbgpu_ntt is in place: the call ALONE is inside the timer, on a ring of three pre-filled pageable buffers (the refill happens outside it;
+        # round 3 timed `refill + call` and subtracted a separately timed refill, which moved the figure by 20 % between boxes)
+        def ntt_boundary(src, kind, reps=10, warm=3):
+            ring = [src.copy() for _ in range(3)]
+            ts = []
+            for i in range(warm + reps):
+                buf = ring[i % 3]
+                buf[...] = src
+                t0 = time.perf_counter()
+                G.ntt(buf, kind)
+                if i >= warm:
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts)), float(min(ts))
         bn = {}
         for kind in ("fft", "coset_fft"):
-            def one_ntt():
-                host_co[...] = ntt_in
-                G.ntt(host_co, kind)
-            t_copy, _ = median_ms(lambda: host_co.__setitem__(Ellipsis, ntt_in), 5, 1)
-            t_all, _ = median_ms(one_ntt, 10, 3)
-            bn[kind] = {"ms": t_all - t_copy, "elements_per_s": n / ((t_all - t_copy) * 1e-3)}
-        host22 = ntt22_in.copy()
-
-        def one_ntt22():
-            host22[...] = ntt22_in
-            G.ntt(host22, "fft")
-        t_copy22, _ = median_ms(lambda: host22.__setitem__(Ellipsis, ntt22_in), 5, 1)
-        t22, _ = median_ms(one_ntt22, 10, 3)
+            t_med, t_min = ntt_boundary(ntt_in, kind)
+            bn[kind] = {"ms": t_med, "ms_min": t_min, "elements_per_s": n / (t_med * 1e-3)}
+        t22, t22_min = ntt_boundary(ntt22_in, "fft")
         boundary = {"note": "wall-clock around the C-ABI calls with pageable host buffers, PCIe included; median of 10 after 3 warm-ups; SRS resident (its one-time upload excluded)",
                     "msm_g1_2e20": {"call": "bbgpu_msm_g1 (pippenger)", "ms": b_msm, "ms_min": b_msm_min, "points_per_s": n / (b_msm * 1e-3), "h2d_bytes": 32 * n},
                     "msm_g1_batch_3x2e20": {"call": "bbgpu_msm_g1_batch (batched_scalar_multiplications), 3 jobs", "ms_per_msm": b_bat / 3, "ms_per_msm_min": b_bat_min / 3,
                                             "points_per_s": 3 * n / (b_bat * 1e-3)},
                     "ntt_2e20": {"call": "bbgpu_ntt (fft / coset_fft)", "fft": bn["fft"], "coset_fft": bn["coset_fft"], "h2d_plus_d2h_bytes": 64 * n},
-                    "ntt_2e22_fft": {"ms": t22 - t_copy22, "elements_per_s": n22 / ((t22 - t_copy22) * 1e-3)}}
+                    "ntt_2e22_fft": {"ms": t22, "ms_min": t22_min, "elements_per_s": n22 / (t22 * 1e-3)}}
 
     # ---- BASELINE config 5 (rank 0 only, reported beside the headline): the resident PLONK prover on a 2^16-gate circuit ----------
     plonk = None
@@ -688,12 +776,16 @@ def main():
         # HBM bytes per launch from the PMC passes of the SAME binary (profiles/, tools/pmc_summary.py), corrected by the factor the
         # gather calibration kernel of known traffic gave for this access shape
         traffic = ntt_traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % t) for t in ("r03", "r02")) if os.path.exists(q)), "")
+        traffic_source = None
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % t) for t in ("r04", "r03", "r02")) if os.path.exists(q)), "")
         if tpath:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("msm_accumulate_kernel_bytes_per_launch")
                 ntt_traffic = tj.get("ntt_2e20_bytes_per_transform")
+                # NOT measured in this run: the counter passes need rocprofv3 around the process (tools/collect_profiles.sh); the figure is the committed one
+                traffic_source = "%s (rocprofv3 --pmc passes on the builder's box, tools/collect_profiles.sh; library of that run: %s; this run's library: %s)" % (
+                    os.path.relpath(tpath, ROOT), tj.get("library_sha256_16", "not recorded"), lib_sha16())
             except Exception:
                 traffic = None
         # the same fraction from the committed rocprofv3 trace of this command (profiles/: spacing of consecutive accumulation dispatches'
@@ -733,6 +825,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32x9 (256-bit Montgomery, 29-bit limbs)",
             "data": "synthetic",
+            "library_sha256_16": lib_sha16(),
             "value_boundary": (n / (boundary["msm_g1_2e20"]["ms"] * 1e-3)) if boundary is not None else None,  # points/s through the host-pointer drop-in call bbgpu_msm_g1, PCIe included
             "config": {"workload": "2^%d-point BN254 G1 MSM, splitmix64 scalars (< 2^252, Montgomery form) vs synthetic SRS x^i*G, inputs resident in HBM, result normalised" % args.log2n,
                        "one_time_costs": {"note": "paid once per SRS / per transform size, excluded from every timed figure",
@@ -749,7 +842,7 @@ def main():
                                          "slices_collect": float(stage_pipe[6]),
                                          "note": "two MSMs in flight, a separate run after the timed region with an event after every stage: stages of consecutive steps overlap, so they sum to more than ms_per_step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "msm_accumulate_kernel", "kernel_ms": acc_ms, "kernel_ms_events_raw": acc_raw_ms, "kernel_ms_alone": float(stage[3]),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "msm_accumulate_kernel", "kernel_ms": acc_ms, "kernel_ms_events_raw": acc_raw_ms, "kernel_ms_alone": float(stage[3]),
                          "frac_from_rocprof_spacing": rocprof_frac, "rocprof_spacing_ms": rocprof_spacing_ms,
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes,
                          "valu": {"bound": "VALU instruction issue of the mixed addition's instruction stream at the measured per-instruction rates",
@@ -772,6 +865,8 @@ def main():
             line["sharded_result_equals_single_gpu"] = sharded_ok
         if window_split is not None:
             line["window_split"] = window_split
+        if per_rank is not None:
+            line.update(per_rank)
         if plonk is not None:
             line["plonk"] = plonk
         if cpu_leg:

@@ -53,6 +53,25 @@ int bbgpu_device_count(void);
 const char* bbgpu_last_error(void);
 const char* bbgpu_version(void);
 
+/* Device memory the library holds for the life of the process ("one-time" state: excluded from every timed figure, but a shared GPU has to plan for it).
+ * Everything here is bounded: the point tables registered on first sight by BBGPU_SRS_CACHE_BYTES (16 GiB, least recently used first; explicitly registered
+ * ones until bbgpu_srs_release), the window tables of one SRS by BBGPU_TABLE_MAX_BYTES (64 GiB), the transforms' twiddle / twist tables -- 128 MiB per 2^20
+ * domain, 512 MiB per 2^22 -- by BBGPU_NTT_TABLE_BYTES (8 GiB, least recently used domain sizes dropped and rebuilt on demand), the workspaces by the largest
+ * call seen (eight MSM slots, scalar staging, transform scratch). */
+typedef struct {
+    uint64_t srs_points_bytes;    /* resident base points of all live tables */
+    uint64_t srs_table_bytes;     /* their pre-shifted window tables */
+    uint64_t srs_auto_bytes;      /* of the two above: held by tables registered on first sight (evictable under srs_cache_cap_bytes) */
+    uint64_t srs_cache_cap_bytes;
+    uint64_t ntt_table_bytes;     /* twiddle / twist / coset tables of the cached domain sizes */
+    uint64_t ntt_table_cap_bytes;
+    uint64_t ntt_table_sets;      /* how many domain sizes are cached */
+    uint64_t msm_workspace_bytes; /* the MSM slots' workspaces (allocated on first use of a slot, sized by its largest MSM) */
+    uint64_t staging_bytes;       /* scalar / coefficient staging, transform scratch, polynomial temporaries */
+    uint64_t pinned_host_bytes;   /* pinned host memory: staging buffers and the slots' result arrays */
+} bbgpu_memory_info;
+int bbgpu_memory_stats(bbgpu_memory_info* out);
+
 /* ---- NTT ---------------------------------------------------------------------------------------------------------
  * Drop-in for polynomial_arithmetic::{fft,ifft,coset_fft,coset_ifft,fft_with_constant,ifft_with_constant,
  * coset_fft_with_constant}(fr::field_t* coeffs, const evaluation_domain& domain[, const fr::field_t& constant]):

@@ -286,3 +286,39 @@ def test_concurrent_callers_of_the_drop_in_entries(gpu, oracle, golden):
     assert not errors, errors
     assert np.array_equal(out[0:4], limbs(want_big["x"])) and np.array_equal(out[4:8], limbs(want_big["y"]))
     gpu.srs_release(h)
+
+
+def test_transform_tables_stay_under_their_byte_budget(gpu, oracle, golden):
+    """the twiddle / twist tables are built per domain size (128 MiB at 2^20, 512 MiB at 2^22) and used to stay for the life of
+    the process.  Under BBGPU_NTT_TABLE_BYTES = 1 GiB a walk through the domains 2^10 .. 2^24 (twice: the second pass rebuilds what the first
+    evicted) keeps bbgpu_memory_stats().ntt_table_bytes under the budget, and every output still equals the oracle's (to 2^16), the reference's
+    digests (2^20, 2^22) or survives the round trip (the sizes between and 2^23 / 2^24, three-pass transforms holding two table sets at once)."""
+    from tests.util import sha
+    g = golden("ntt.json")
+    const = limbs(g["constant"])
+    cap = 1 << 30
+    os.environ["BBGPU_NTT_TABLE_BYTES"] = str(cap)
+    try:
+        seen_sets = []
+        for sweep in range(2):
+            for lg in list(range(10, 25)):
+                n = 1 << lg
+                if lg <= 16:
+                    co = noncanonical(oracle.random_scalars(NTT_SEED + lg, n), FR_MODULUS)
+                    for kind in ("fft", "coset_ifft"):
+                        assert np.array_equal(gpu.ntt(co.copy(), kind), oracle.ntt(co, kind)), (sweep, lg, kind)
+                elif lg in (20, 22):
+                    co = noncanonical(oracle.random_scalars(NTT_SEED, n), FR_MODULUS)
+                    for case in [x for x in g["large"] if x["n"] == n and x["kind"] in ("fft", "coset_fft_with_constant")]:
+                        assert sha(gpu.ntt(co.copy(), case["kind"], const)) == case["sha256"], (sweep, lg, case["kind"])
+                else:
+                    x = oracle.random_scalars(NTT_SEED + 900 + lg, n)
+                    assert np.array_equal(gpu.coset_ifft(gpu.coset_fft(x.copy())), x), (sweep, lg)
+                m = gpu.memory_stats()
+                assert m["ntt_table_cap_bytes"] == cap and m["ntt_table_bytes"] <= cap, (sweep, lg, m)
+                seen_sets.append(m["ntt_table_sets"])
+        assert max(seen_sets) < 15 and seen_sets[-1] >= 1  # something was evicted on the way: 15 domain sizes were walked (plus the row domains of 2^23 / 2^24)
+    finally:
+        del os.environ["BBGPU_NTT_TABLE_BYTES"]
+    m = gpu.memory_stats()
+    assert m["msm_workspace_bytes"] >= 0 and m["staging_bytes"] > 0 and m["pinned_host_bytes"] > 0

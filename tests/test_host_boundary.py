@@ -305,3 +305,26 @@ def test_bench_input_generator_is_splitmix64():
         assert [int(v) for v in sc[i]] == want[4 * i:4 * i + 3] + [want[4 * i + 3] & 0x0FFFFFFFFFFFFFFF]
     assert all(sum(int(v) << (64 * k) for k, v in enumerate(s)) < (1 << 252) for s in sc)
     assert [int(v) for v in bench.limbs_of(pow(2, 512, bench.FR_MODULUS))] == [0x1BB8E645AE216DA7, 0x53FE3AB1E35C59E3, 0x8C49833D53BB8085, 0x0216D0B17F4E44A5]  # fr.hpp:49-52 r_squared
+
+
+def test_shipped_kernels_read_no_result_changing_variable():
+    """VERDICT r3 #7c: the phase ablation of the transform kernels (skip stages / twists: wrong transforms) is a BUILD variant
+    (-DBBGPU_NTT_DEBUG_SKIP), like the JUNK issue-model knobs; no environment variable of the shipped library changes results"""
+    import re
+    src = os.path.join(ROOT, "barretenberg_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if not f.endswith((".hip", ".hpp", ".h")):
+            continue
+        text = open(os.path.join(src, f), errors="replace").read()
+        for m in re.finditer(r'getenv\(\s*"([A-Z0-9_]+)"', text):
+            assert not re.search(r"SKIP|DEBUG|JUNK", m.group(1)), (f, m.group(1))
+    ntt = open(os.path.join(src, "ntt.hip")).read()
+    assert "constexpr uint32_t NTT_DEBUG_SKIP = 0;" in ntt and "debug_skip" not in ntt
+
+
+def test_environment_variable_table_is_generated_from_the_sources():
+    """INTEGRATION.md lists every BBGPU_* variable the product reads; tools/gen_env_table.py --check fails when the list is stale"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_env_table.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr or r.stdout

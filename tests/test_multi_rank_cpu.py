@@ -138,7 +138,32 @@ def _pipeline_worker(rank, world, port, ret):
     for s in range(steps):
         want = mul((s + 1) * 2 + ((s + 1) * 3 if s != 3 else 0))
         ok = ok and bool(np.array_equal(got[s][:8], want[:8]))
+    # the coalesced exchange bench.py uses for N > 1: the partial sums of `group` steps in ONE all-gather of group x 96 bytes (7 steps in groups
+    # of 3, 3, 1: the tail group is padded with infinity), every MSM still folded from its own N partial sums, results in step order; with the
+    # shares issued by the helper thread (issuer=True) and the per-step host clock bench.py reports
+    from barretenberg_amd.sharding import StepClock
+    for group, issuer, depth in ((3, False, 2), (3, True, 4), (4, True, 4), (2, True, 1)):
+        issued.clear()
+        clock = StepClock()
+        got = pipelined_steps(steps, issue, collect, PartialSumExchange(lib, world, torch.device("cpu"), group=group), depth=depth, clock=clock, issuer=issuer)
+        ok = ok and len(got) == steps and issued == list(range(steps)) and clock.steps == steps
+        ok = ok and set(clock.per_step_us()) == {"issue", "wait", "exchange_start", "exchange_finish"} and clock.per_step_us()["exchange_start"] > 0
+        for s in range(steps):
+            want = mul((s + 1) * 2 + ((s + 1) * 3 if s != 3 else 0))
+            ok = ok and bool(np.array_equal(got[s][:8], want[:8]))
+    # an exception on the issuing thread reaches the caller
+    def bad_issue():
+        if len(issued) == 2:
+            raise RuntimeError("issue failed")
+        return issue()
+    issued.clear()
+    try:
+        pipelined_steps(steps, bad_issue, collect, None, depth=2, issuer=True)
+        ok = False
+    except RuntimeError:
+        pass
     # world == 1 semantics: no exchange, partial sums come back as they are
+    issued.clear()
     solo = pipelined_steps(3, issue, lambda t: mul(t + 1), None)
     ok = ok and len(solo) == 3
     t = torch.tensor([1 if ok else 0])
@@ -176,7 +201,7 @@ def _run_bench(args, env_extra=None, timeout=300):
 def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus N` (the driver's command form) with no launcher around it: the parent starts N fresh rank processes before
     anything touches torch / HIP, the ranks form ONE process group of size N, rank 0's line comes through the parent's stdout"""
-    r, lines = _run_bench(["--gpus", "3", "--probe"])
+    r, lines = _run_bench(["--gpus", "3", "--probe", "--backend", "gloo"])
     assert r.returncode == 0, r.stderr
     assert len(lines) == 1
     p = lines[0]
@@ -186,12 +211,12 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
 
 
 def test_bench_launcher_reports_a_failed_rank():
-    r, lines = _run_bench(["--gpus", "2", "--probe"], {"BBGPU_BENCH_PROBE_FAIL_RANK": "1"})
+    r, lines = _run_bench(["--gpus", "2", "--probe", "--backend", "gloo"], {"BBGPU_BENCH_PROBE_FAIL_RANK": "1"})
     assert r.returncode == 7 and "rank 1 exited with 7" in r.stderr
 
 
 def test_bench_refuses_a_world_size_that_contradicts_the_flag():
-    r, lines = _run_bench(["--gpus", "4", "--probe"], {"WORLD_SIZE": "2", "RANK": "0", "MASTER_PORT": "29999"})
+    r, lines = _run_bench(["--gpus", "4", "--probe", "--backend", "gloo"], {"WORLD_SIZE": "2", "RANK": "0", "MASTER_PORT": "29999"})
     assert r.returncode == 2 and not lines and "WORLD_SIZE=2" in r.stderr
 
 
@@ -204,7 +229,18 @@ def test_bench_under_torch_distributed_run():
         env.pop(k, None)
     port = 32500 + (os.getpid() % 2000)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--probe"], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--probe", "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and lines[0]["launcher_pid"] == 0
+
+
+def test_bench_probe_over_nccl_fails_loudly_without_gpus():
+    """`--probe --backend nccl` (the default backend) is the RCCL sanity line of an N > 1 run: on a machine that cannot form the group it exits
+    non-zero with the reason -- it never switches to gloo behind the caller's back"""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    r, lines = _run_bench(["--gpus", "2", "--probe"])
+    assert r.returncode != 0 and not lines
+    assert "could not join the nccl process group" in r.stderr and "GPU" in r.stderr

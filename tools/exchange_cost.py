@@ -27,7 +27,10 @@ def old_step():
 
 ex = PartialSumExchange(G, 1, dev)
 new_step = lambda: ex.finish(ex.start(part))
-for name, fn in (("per-step allocation (round 1)", old_step), ("preallocated ring", new_step)):
+ex4 = PartialSumExchange(G, 1, dev, group=4)
+four = [part] * 4
+for name, fn, per in (("per-step allocation (round 1)", old_step, 1), ("preallocated ring", new_step, 1),
+                      ("one all-gather of 4 x 96 B per 4 steps (round 4)", lambda: ex4.finish(ex4.start(four)), 4)):
     for _ in range(50):
         fn()
     ts = []
@@ -36,5 +39,5 @@ for name, fn in (("per-step allocation (round 1)", old_step), ("preallocated rin
         for _ in range(200):
             fn()
         ts.append((time.perf_counter() - t0) / 200)
-    print("%-32s %.1f us per exchange step (median of 5 x 200)" % (name, float(np.median(ts)) * 1e6), flush=True)
+    print("%-50s %.1f us per exchange = %.1f us per MSM step (median of 5 x 200)" % (name, float(np.median(ts)) * 1e6, float(np.median(ts)) * 1e6 / per), flush=True)
 dist.destroy_process_group()

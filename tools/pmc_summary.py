@@ -35,6 +35,16 @@ def load(d, counter):
     return acc
 
 
+def lib_sha16():
+    """which libbbgpu.so the counter passes ran (bench.py prints the same digest of the library IT loaded: roofline.traffic_source)"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        return hashlib.sha256(open(os.environ.get("BBGPU_LIB") or os.path.join(root, "barretenberg_amd", "libbbgpu.so"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def mean(v):
     return sum(v) / len(v) if v else 0.0
 
@@ -72,6 +82,7 @@ def main():
     ntt_total = sum(v["total_bytes"] * v["launches"] for v in ntt) / max(1, sum(v["launches"] for v in ntt)) * 2 if ntt else None
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing domains) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary; "
                      "calibration: the same two passes -- tools/ubench/ubench_traffic",
+           "library_sha256_16": lib_sha16(),
            "units": "Counter_Value is KiB; bytes = value * 1024; means per launch; *_raw as counted, the others multiplied by the factor of the kernel's access shape",
            "calibration": calib,
            "msm_accumulate_kernel_bytes_per_launch": acc.get("total_bytes"),
