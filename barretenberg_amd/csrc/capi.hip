@@ -107,9 +107,13 @@ struct Context {
     size_t poly_tmp_cap = 0;
     MsmTiming last;
     // pinned staging for the callers' host buffers (host_to_device / device_to_host_sync)
-    static constexpr size_t HOST_CHUNK = (size_t)4 << 20;
-    void* h_stage[2] = { nullptr, nullptr };
-    hipEvent_t h_stage_free[2] = { nullptr, nullptr };
+    // 8 x 1 MiB (round 3: 2 x 4 MiB): the first chunk reaches the link after 1 MiB of CPU copy instead of 4, and up to seven chunks are queued behind
+    // it -- bbgpu_ntt at 2^18 (8 MiB each way) 0.651 -> 0.617 ms, the reference prover on the shim level within its own noise (tools/stage_chunk_ab.sh)
+    static constexpr size_t HOST_CHUNK = (size_t)1 << 20; // bytes per pinned staging buffer
+    static constexpr int HOST_RING = 8;                   // staging buffers (a ring: the CPU copies run ahead of the DMA of the chunks before them)
+    size_t host_chunk = HOST_CHUNK;                       // bytes of a buffer actually used per chunk (BBGPU_STAGE_CHUNK_BYTES <= HOST_CHUNK)
+    void* h_stage[HOST_RING] = {};
+    hipEvent_t h_stage_free[HOST_RING] = {};
     unsigned h_stage_next = 0;
     size_t host_stage_max = (size_t)8 << 20; // BBGPU_STAGE_MAX_BYTES: larger buffers are handed to hipMemcpyAsync as they are
 };
@@ -133,6 +137,7 @@ void read_host_env()
     if (const char* e = getenv("BBGPU_HOST_MSM_MAX")) g_ctx.host_msm_max = atoi(e);
     if (const char* e = getenv("BBGPU_HOST_NTT_MAX")) g_ctx.host_ntt_max = std::min(64, atoi(e));
     if (const char* e = getenv("BBGPU_STAGE_MAX_BYTES")) g_ctx.host_stage_max = (size_t)strtoull(e, nullptr, 0);
+    if (const char* e = getenv("BBGPU_STAGE_CHUNK_BYTES")) g_ctx.host_chunk = std::min(Context::HOST_CHUNK, std::max((size_t)64 << 10, (size_t)strtoull(e, nullptr, 0))); // tuning knob
 }
 
 int ensure_init()
@@ -140,7 +145,7 @@ int ensure_init()
     if (g_ctx.ready) return BBGPU_OK;
     // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of two streams that
     // share a queue run one after the other.  With the caller's streams beside them the four MSM slot streams landed on TWO queues: "three in
-    // flight" was slower than two for that reason alone (rocprofv3 timeline; 2^16-point MSMs three in flight 0.168 -> 0.127 ms per
+    // flight" was slower than two for that reason alone (rocprofv3 timeline, DESIGN_HISTORY.md 6; 2^16-point MSMs three in flight 0.168 -> 0.127 ms per
     // MSM with 8 queues, a 1/8 share four in flight 0.232 -> 0.205).  16: the eight slot streams, the library's own and the caller's.  Only effective when this is the process's first HIP call; a host
     // program that initialises HIP earlier sets the variable itself (bench.py and the Python binding do).
     (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
@@ -205,6 +210,15 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
 // stall is small against the work (profiles/r03_pcie.txt).
 static host::CopyPool g_copy_pool; // CPU copies into / out of the pinned staging buffers (host_copy_pool.hpp)
 
+static int host_stage_ensure()
+{
+    for (int k = 0; k < Context::HOST_RING; k++)
+        if (!g_ctx.h_stage[k]) {
+            CHK(hipHostMalloc(&g_ctx.h_stage[k], Context::HOST_CHUNK, hipHostMallocDefault));
+            CHK(hipEventCreateWithFlags(&g_ctx.h_stage_free[k], hipEventDisableTiming));
+        }
+    return BBGPU_OK;
+}
 // Both directions take the library mutex themselves (recursive: the capi entry points already hold it): the resident prover's uploads
 // (plonk.hip, which holds only its own mutex) would otherwise race with a transform or an MSM of another thread on the staging buffers,
 // their events and the single-producer copy pool.  Lock order everywhere: the prover's mutex first, then this one.
@@ -217,15 +231,11 @@ int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
         CHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
         return BBGPU_OK;
     }
-    const size_t CH = Context::HOST_CHUNK;
-    for (int k = 0; k < 2; k++)
-        if (!g_ctx.h_stage[k]) {
-            CHK(hipHostMalloc(&g_ctx.h_stage[k], CH, hipHostMallocDefault));
-            CHK(hipEventCreateWithFlags(&g_ctx.h_stage_free[k], hipEventDisableTiming));
-        }
+    if (int rc = host_stage_ensure()) return rc;
+    const size_t CH = g_ctx.host_chunk;
     for (size_t off = 0; off < bytes; off += CH) {
         const size_t len = std::min(CH, bytes - off);
-        const int k = (int)(g_ctx.h_stage_next++ & 1);
+        const int k = (int)(g_ctx.h_stage_next++ % Context::HOST_RING);
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k])); // the DMA that last read this buffer has finished (no-op before its first use)
         g_copy_pool.copy(g_ctx.h_stage[k], (const char*)h_src + off, len);
         CHK(hipMemcpyAsync((char*)d_dst + off, g_ctx.h_stage[k], len, hipMemcpyHostToDevice, st));
@@ -243,18 +253,15 @@ int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_
         CHK(hipStreamSynchronize(st));
         return BBGPU_OK;
     }
-    const size_t CH = Context::HOST_CHUNK;
-    for (int k = 0; k < 2; k++)
-        if (!g_ctx.h_stage[k]) {
-            CHK(hipHostMalloc(&g_ctx.h_stage[k], CH, hipHostMallocDefault));
-            CHK(hipEventCreateWithFlags(&g_ctx.h_stage_free[k], hipEventDisableTiming));
-        }
-    // chunk c+1 is on the link while chunk c is copied out of its pinned buffer
+    if (int rc = host_stage_ensure()) return rc;
+    // up to HOST_RING - 1 chunks are on the link (or queued for it) while one is copied out of its pinned buffer
+    const size_t CH = g_ctx.host_chunk;
     const size_t chunks = (bytes + CH - 1) / CH;
-    int kbuf[2] = { 0, 0 };
+    constexpr size_t AHEAD = Context::HOST_RING - 1;
+    int kbuf[Context::HOST_RING] = {};
     auto enqueue = [&](size_t c) -> int {
-        const int k = (int)(g_ctx.h_stage_next++ & 1);
-        kbuf[c & 1] = k;
+        const int k = (int)(g_ctx.h_stage_next++ % Context::HOST_RING);
+        kbuf[c % Context::HOST_RING] = k;
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k]));
         CHK(hipMemcpyAsync(g_ctx.h_stage[k], (const char*)d_src + c * CH, std::min(CH, bytes - c * CH), hipMemcpyDeviceToHost, st));
         CHK(hipEventRecord(g_ctx.h_stage_free[k], st));
@@ -264,11 +271,15 @@ int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_
         CHK(hipStreamSynchronize(st));
         return BBGPU_OK;
     }
-    if (int rc = enqueue(0)) return rc;
+    size_t queued = 0;
+    for (; queued < chunks && queued < AHEAD; queued++)
+        if (int rc = enqueue(queued)) return rc;
     for (size_t c = 0; c < chunks; c++) {
-        if (c + 1 < chunks)
-            if (int rc = enqueue(c + 1)) return rc;
-        const int k = kbuf[c & 1];
+        if (queued < chunks) {
+            if (int rc = enqueue(queued)) return rc;
+            queued++;
+        }
+        const int k = kbuf[c % Context::HOST_RING];
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k]));
         g_copy_pool.copy((char*)h_dst + c * CH, g_ctx.h_stage[k], std::min(CH, bytes - c * CH));
     }
@@ -278,7 +289,7 @@ void host_stage_release()
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     g_copy_pool.shutdown();
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < Context::HOST_RING; k++) {
         if (g_ctx.h_stage[k]) (void)hipHostFree(g_ctx.h_stage[k]);
         if (g_ctx.h_stage_free[k]) (void)hipEventDestroy(g_ctx.h_stage_free[k]);
         g_ctx.h_stage[k] = nullptr;
@@ -492,7 +503,7 @@ void drain_ticket(int t)
 // Issues `jobs` MSMs (one scalar vector each) over points [off, off + n) of entry e, windows [wb, we), on slot t; `st` = the caller's stream or the
 // slot's own.  Inside one table segment (every SRS up to 2^20 points) that is one pass through the kernels.  A range that spans several segments
 // is issued as one PIECE per segment, dealt alternately to slot t and -- when one is free -- a HELPER slot with its own stream and workspace, so
-// that the digit / sort front of piece k + 1 runs beside the accumulation of piece k exactly as two consecutive MSMs do; the helper
+// that the digit / sort front of piece k + 1 runs beside the accumulation of piece k exactly as two consecutive MSMs do (DESIGN_HISTORY 5); the helper
 // is ordered behind the producer of the scalars by an event when the caller gave a stream.  The ticket stays slot t: finish_ticket() adds up
 // both slots' pieces.
 int issue_ticket(int t, const SrsEntry& e, size_t off, const uint64_t* const* d_scalars_v, int jobs, size_t n, int wb, int we, hipStream_t st)
@@ -855,7 +866,7 @@ int bbgpu_memory_stats(bbgpu_memory_info* out)
         if (sl.ws.h_out) out->pinned_host_bytes += (uint64_t)MSM_HOUT_GROUPS * 64 * 128;
     }
     out->staging_bytes = g_ctx.stage_cap + g_ctx.stage2_cap + g_ctx.scratch_cap + g_ctx.poly_tmp_cap + g_ctx.poly_scratch.cap;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < Context::HOST_RING; k++)
         if (g_ctx.h_stage[k]) out->pinned_host_bytes += Context::HOST_CHUNK;
     return BBGPU_OK;
 }

@@ -117,7 +117,7 @@ template <int V> BB_HD void madd(Xyzz& acc, const AffineV<V>& a)
 }
 
 // The same for the bucket accumulation's hot loop (msm_accumulate_kernel), written around what that loop pays for besides its ten
-// products (round 3; the instruction counts are those of the gfx950 ISA):
+// products (round 3; the instruction counts are those of the gfx950 ISA, DESIGN_HISTORY.md 5):
 //  * the accumulator's infinity is a FLAG (set at a bucket start and by P + (-P)); the caller takes the `acc = a` branch itself, so
 //    this function only sees a finite accumulator -- and sets the flag (and a clean infinity) when the sum cancels;
 //  * the results land in the accumulator's own registers: ZZ3, ZZZ3 and Y3 are in-place products (mul_ip / mul_add_ip, the result

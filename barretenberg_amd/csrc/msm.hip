@@ -1015,7 +1015,7 @@ __global__ void __launch_bounds__(MSM_THREADS) ACC_VGPR_CAP msm_accumulate_kerne
         }
         asm volatile("" ::: "memory");
         if (!start) madd_ip(acc, acc_inf, px, py);
-#ifdef BBGPU_ACC_JUNK // issue-model experiment: extra cheap VALU instructions per trip, results unused
+#ifdef BBGPU_ACC_JUNK // issue-model experiment (DESIGN_HISTORY 5): extra cheap VALU instructions per trip, results unused
         {
             uint32_t j0 = e, j1 = vn;
 #pragma unroll

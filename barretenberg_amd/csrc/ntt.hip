@@ -31,7 +31,7 @@
 namespace bbgpu {
 
 using Fr = FrP;
-// Phase ablation for timing experiments: a BUILD variant like the JUNK knobs (make variant NAME=nttskip1 EXTRA=-DBBGPU_NTT_DEBUG_SKIP=1),
+// Phase ablation for timing experiments (DESIGN_HISTORY 4): a BUILD variant like the JUNK knobs (make variant NAME=nttskip1 EXTRA=-DBBGPU_NTT_DEBUG_SKIP=1),
 // never an environment variable -- the shipped kernels have no switch that changes results.  Bit 0: skip the stages, bit 1: skip the twist / scaling products.
 #ifdef BBGPU_NTT_DEBUG_SKIP
 constexpr uint32_t NTT_DEBUG_SKIP = BBGPU_NTT_DEBUG_SKIP;
@@ -363,7 +363,7 @@ __device__ __forceinline__ Radix4Out radix4_lazy(const FrS& x0, const FrS& x1, c
     const auto a2 = add(x2, t3);                                                // 5 U
     const auto a3 = sub(x2, t3);                                                // 6 U: the multiplier's limit
     const auto u2 = exact_limbs(mul(w2a, a2)), u3 = exact_limbs(mul(w2b, a3));
-#ifdef BBGPU_NTT_JUNK // issue-model experiment: k extra cheap VALU instructions per multiplication of a stage pair, results unused
+#ifdef BBGPU_NTT_JUNK // issue-model experiment (DESIGN_HISTORY 4): k extra cheap VALU instructions per multiplication of a stage pair, results unused
     {
         uint32_t j0 = x0.d[0], j1 = x1.d[0];
 #pragma unroll

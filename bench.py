@@ -83,7 +83,7 @@ if __name__ == "__main__":
     if _rc is not None:
         sys.exit(_rc)
 
-# before HIP is initialised: the MSM slot streams get hardware queues of their own.  A rehearsal that puts all ranks on ONE GPU (--same-device) shares
+# before HIP is initialised: the MSM slot streams get hardware queues of their own (DESIGN_HISTORY.md 6).  A rehearsal that puts all ranks on ONE GPU (--same-device) shares
 # that GPU's hardware queues between the ranks: 4 ranks x 16 queues oversubscribe them and the GPU time-slices the processes (13 ms per step instead of 1.5)
 _ranks_on_one_gpu = int(os.environ.get("WORLD_SIZE", "1")) if "--same-device" in sys.argv else 1
 os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 32 // _ranks_on_one_gpu)) if _ranks_on_one_gpu > 1 else "16")
@@ -700,7 +700,7 @@ def main():
             while infl:
                 G.msm_wait(infl.pop(0))
         pipe16, _ = median_ms(lambda: in_flight(2, 10), 10, 2)
-        pipe16_3, _ = median_ms(lambda: in_flight(3, 12), 10, 2)  # small MSMs are chains of short launches: a third one in flight still fits (hardware queues: DESIGN.md 6 iv)
+        pipe16_3, _ = median_ms(lambda: in_flight(3, 12), 10, 2)  # small MSMs are chains of short launches: a third one in flight still fits (hardware queues: DESIGN_HISTORY.md 6 iv)
         res16 = G.msm_device(h16, d_scalars.data_ptr(), m)
         config1 = {"workload": "2^16-point G1 MSM (BASELINE config 1 on the GPU), inputs resident", "latency_ms": lat16, "latency_ms_min": lat16_min,
                    "ms_per_msm_two_in_flight": pipe16 / 10, "ms_per_msm_three_in_flight": pipe16_3 / 12, "points_per_s": m / (min(pipe16 / 10, pipe16_3 / 12) * 1e-3)}
@@ -803,7 +803,7 @@ def main():
         share_adds = (W * (pt1 - pt0)) if by_points else (W * n // world) if by_buckets else (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation (expected, for bucket shares)
         # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition (round-3 loop: 2,142 instructions in the hot
         # path + ~85 in the bucket-start block that ~1 trip in 4 runs) = 738 v_mad_u64_u32 with two VGPR factors + 729 with an SGPR factor
-        # + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 194 v_and_b32 + ~275 other VALU, priced at the measured chip-wide issue rates of
+        # + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 194 v_and_b32 + ~275 other VALU (DESIGN_HISTORY.md 5), priced at the measured chip-wide issue rates of
         # tools/ubench/ubench_inst (445 / 489 / 565 / 537 / 916 / ~850 G wave-instructions/s): 4.04 ns of chip time per wave-addition = the
         # floor this instruction stream allows (round 2: 209 ands, ~430 others, 4.24 ns)
         ns_per_wave_add = 738 / 445.0 + 729 / 489.0 + 144 / 565.0 + 81 / 537.0 + 194 / 916.0 + 275 / 850.0

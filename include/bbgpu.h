@@ -154,7 +154,7 @@ int bbgpu_srs_generate_range(const uint64_t* x_mont, size_t first, size_t n, uin
  * encoding (tests/test_gpu_plonk.py::test_commitments_at_infinity).  Every other result is the unique affine point and is bit-identical.
  * From 2^19 points on the call runs as two point ranges through the two-slot pipeline (the second range's scalars cross the link under the
  * first one's kernels; BBGPU_HOST_MSM_SPLIT).  Host buffers of up to 8 MiB (BBGPU_STAGE_MAX_BYTES) are copied through the library's own
- * pinned staging buffers rather than pinned in place by the runtime. */
+ * pinned staging buffers rather than pinned in place by the runtime (DESIGN_HISTORY.md 1). */
 int bbgpu_msm_g1(const uint64_t* scalars, const uint64_t* points_endo_table, size_t n, uint64_t out[12]);
 /* the same sum over a PLAIN table: `points` = n affine points, 64 bytes apart -- the argument convention of the reference's
  * pippenger_low_memory(scalars, points, num_points) (scalar_multiplication.cpp:142-262, which applies beta itself; its test allocates
@@ -189,10 +189,10 @@ int bbgpu_msm_num_windows(size_t n);
 int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                         int window_end, uint64_t out[12], void* hip_stream);
 /* Asynchronous form: enqueue (returns a ticket >= 0, or a negative error) and collect later.  Up to eight MSMs may be in
- * flight; the bucket-reduction tail and host finish of one then overlap the sort/accumulate of the next, and
+ * flight; the bucket-reduction tail and host finish of one then overlap the sort/accumulate of the next (DESIGN_HISTORY.md 5), and
  * small latency-bound MSMs (a prover round's three commitments) run side by side.  With hip_stream == NULL each ticket runs
  * on its own internal stream.  An MSM enqueued while another is in flight is laid out for throughput instead of latency (longer
- * accumulation chunks, row / column sums in two steps: DESIGN.md 5, 6 v); the result is the same point either way. */
+ * accumulation chunks, row / column sums in two steps: DESIGN_HISTORY.md 5, 6 v); the result is the same point either way. */
 int bbgpu_msm_g1_device_async(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                               int window_end, void* hip_stream);
 /* The same with a share that may start and end INSIDE a digit window: rows [row_begin, row_end) of the W x n (window, point) pairs counted
