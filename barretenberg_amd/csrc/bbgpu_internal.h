@@ -85,6 +85,7 @@ int srs_generate(const uint64_t* x_mont256, size_t first, size_t n, uint32_t** d
 int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
 int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st);
 void host_stage_release();
+int bind_calling_thread(); // initialises the library if need be and makes the bound device the calling thread's current one (HIP's current device is per thread)
 
 // plonk.hip
 std::mutex& plonk_mutex();        // taken BEFORE capi.hip's mutex wherever both are held

@@ -142,7 +142,16 @@ void read_host_env()
 
 int ensure_init()
 {
-    if (g_ctx.ready) return BBGPU_OK;
+    if (g_ctx.ready) {
+        // HIP's current device is PER THREAD (device 0 in a fresh one): a caller's worker thread -- the reference's OpenMP threads around pippenger(),
+        // bench.py's issuing thread on rank r > 0 -- must allocate and launch on the device this process is bound to, not on device 0
+        static thread_local int bound_device = -1;
+        if (bound_device != g_ctx.device) {
+            CHK(hipSetDevice(g_ctx.device));
+            bound_device = g_ctx.device;
+        }
+        return BBGPU_OK;
+    }
     // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of two streams that
     // share a queue run one after the other.  With the caller's streams beside them the four MSM slot streams landed on TWO queues: "three in
     // flight" was slower than two for that reason alone (rocprofv3 timeline, DESIGN_HISTORY.md 6; 2^16-point MSMs three in flight 0.168 -> 0.127 ms per
@@ -210,6 +219,11 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
 // stall is small against the work (profiles/r03_pcie.txt).
 static host::CopyPool g_copy_pool; // CPU copies into / out of the pinned staging buffers (host_copy_pool.hpp)
 
+int bind_calling_thread()
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return ensure_init();
+}
 static int host_stage_ensure()
 {
     for (int k = 0; k < Context::HOST_RING; k++)

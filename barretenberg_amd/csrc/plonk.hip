@@ -783,6 +783,7 @@ int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* c, int srs_handle)
         return BBGPU_ERR_ARG;
     }
     std::lock_guard<std::mutex> lk(g_pmu);
+    if (int rcb = bind_calling_thread()) return rcb; // the kernels below are launched from THIS thread
     PlonkProver* p = new PlonkProver();
     int rc = p->init(c, srs_handle);
     if (rc) {
@@ -796,6 +797,7 @@ int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* c, int srs_handle)
 int bbgpu_plonk_prover_set_witness(int prover, const uint64_t* w_l, const uint64_t* w_r, const uint64_t* w_o)
 {
     std::lock_guard<std::mutex> lk(g_pmu);
+    if (int rcb = bind_calling_thread()) return rcb; // the kernels below are launched from THIS thread
     PlonkProver* p = get(prover);
     if (!p || !w_l || !w_r || !w_o) return BBGPU_ERR_ARG;
     return p->set_witness(w_l, w_r, w_o);
@@ -804,6 +806,7 @@ int bbgpu_plonk_prover_set_witness(int prover, const uint64_t* w_l, const uint64
 int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF_WORDS])
 {
     std::lock_guard<std::mutex> lk(g_pmu);
+    if (int rcb = bind_calling_thread()) return rcb; // the kernels below are launched from THIS thread
     PlonkProver* p = get(prover);
     if (!p || !proof_out) return BBGPU_ERR_ARG;
     int rc = p->construct_proof();
@@ -815,6 +818,7 @@ int bbgpu_plonk_construct_proof(int prover, uint64_t proof_out[BBGPU_PLONK_PROOF
 int bbgpu_plonk_preprocess(int prover, uint64_t vk_out[BBGPU_PLONK_VK_WORDS])
 {
     std::lock_guard<std::mutex> lk(g_pmu);
+    if (int rcb = bind_calling_thread()) return rcb; // the kernels below are launched from THIS thread
     PlonkProver* p = get(prover);
     if (!p || !vk_out) return BBGPU_ERR_ARG;
     return p->preprocess(reinterpret_cast<uint64_t(*)[8]>(vk_out));

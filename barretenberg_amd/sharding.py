@@ -109,12 +109,13 @@ class StepClock:
         return {k: (v / self.steps * 1e6 if self.steps else 0.0) for k, v in self.t.items()}
 
 
-def pipelined_steps(k, issue, collect, exchange=None, depth=2, clock=None, issuer=False):
+def pipelined_steps(k, issue, collect, exchange=None, depth=2, clock=None, issuer=False, issuer_device=None):
     """k steps: `issue()` enqueues this rank's share of one MSM and returns a ticket, `collect(ticket)` waits for it and returns
     the rank's partial sum; at most `depth` shares are in flight.  With an exchange (world > 1) the partial sums are folded across
     ranks, `exchange.group` of them per collective, the exchange of one group overlapping the collection of the next.
     issuer=True: the issue() calls run on a helper thread (bounded to `depth` ahead of the collector), the calling thread collects and
-    exchanges.  Returns the results of all k steps in order."""
+    exchanges; issuer_device = the rank's GPU index (the current device is per thread: a fresh thread starts on device 0).
+    Returns the results of all k steps in order."""
     results, pending, batch = [], None, []
     group = exchange.group if exchange is not None else 1
     now = time.perf_counter
@@ -162,6 +163,8 @@ def pipelined_steps(k, issue, collect, exchange=None, depth=2, clock=None, issue
 
         def run():
             try:
+                if issuer_device is not None and torch.cuda.is_available():
+                    torch.cuda.set_device(issuer_device)
                 for _ in range(k):
                     room.acquire()
                     q.put(timed_issue())

@@ -530,7 +530,7 @@ def main():
         """k complete MSMs; step i+1 is enqueued before step i is collected (two-slot pipeline of the library), so the
         bucket-reduction tail + host finish of one step overlap the sort/accumulate of the next; with N > 1 the exchange of
         step i is in flight while step i+1 is collected (barretenberg_amd/sharding.py)"""
-        out = pipelined_steps(k, issue, collect, exchange, depth=depth, clock=clock, issuer=use_issuer)
+        out = pipelined_steps(k, issue, collect, exchange, depth=depth, clock=clock, issuer=use_issuer, issuer_device=local_rank)
         return out[-1] if out else None
 
     def finish(ticket):
@@ -614,7 +614,7 @@ def main():
             return G.msm_device_rows_async(srs_rows, d_scalars.data_ptr(), n, rr[0], rr[1]) if rr[1] > rr[0] else None
 
         def run_rows(k):
-            out = pipelined_steps(k, issue_rows, collect, exchange, depth=depth, issuer=use_issuer)
+            out = pipelined_steps(k, issue_rows, collect, exchange, depth=depth, issuer=use_issuer, issuer_device=local_rank)
             return out[-1] if out else None
 
         run_rows(20 + args.warmup)
