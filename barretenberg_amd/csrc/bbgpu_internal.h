@@ -43,8 +43,8 @@ struct MsmPiece {
     bool trivial = false;
 };
 constexpr int MSM_MAX_JOBS = 4;        // MSMs over the same points issued as one batch (one bucket set each)
-constexpr int MSM_MAX_PIECES = 32;      // per slot
-constexpr uint32_t MSM_HOUT_GROUPS = 128; // 64-slot groups of the pinned result array (pieces x jobs, or the windows of one table-less piece)
+constexpr int MSM_MAX_PIECES = 64;      // per slot: an MSM without a free helper slot keeps all its pieces on one
+constexpr uint32_t MSM_HOUT_GROUPS = 256; // 64-slot groups of the pinned result array (pieces x jobs, or the windows of one table-less piece): 2 MiB per slot
 struct MsmSlot {
     MsmWorkspace ws;
     MsmPiece piece[MSM_MAX_PIECES];

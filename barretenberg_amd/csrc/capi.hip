@@ -379,10 +379,13 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
     // segments: as few as the 24-bit row index allows, equal lengths (multiples of 8: the sort reads eight digits per load).  One up to 2^20 points;
     // beyond that the tables are kept up to BBGPU_TABLE_MAX_BYTES (default 64 GiB = 2^26 points) -- larger tables fall back to per-window bucket sets
     static const uint64_t tab_max_bytes = [] { const char* v = getenv("BBGPU_TABLE_MAX_BYTES"); return v ? strtoull(v, nullptr, 0) : (uint64_t)64 << 30; }();
-    const size_t seg_cap = (size_t)((((uint64_t)1 << 24) / (uint64_t)W) & ~(uint64_t)7);
+    size_t seg_cap = (size_t)((((uint64_t)1 << 24) / (uint64_t)W) & ~(uint64_t)7);
+    // testing knob: smaller segments, so that the piece machinery of the large MSMs can be driven against the oracle at sizes the oracle finishes in seconds
+    // (read at registration; the decomposition changes, the sum does not)
+    if (const char* v = getenv("BBGPU_TABLE_SEG_POINTS")) seg_cap = std::min(seg_cap, std::max<size_t>(64, (size_t)strtoull(v, nullptr, 0) & ~(size_t)7));
     const size_t nseg = (n + seg_cap - 1) / seg_cap;
     const size_t seg_n = nseg <= 1 ? n : ((((n + nseg - 1) / nseg) + 7) & ~(size_t)7);
-    const bool want_tab = g_ctx.precompute && n >= 1024 && (nseg == 1 || ((uint64_t)n * W * 64 <= tab_max_bytes && nseg <= 2 * (size_t)MSM_MAX_PIECES));
+    const bool want_tab = g_ctx.precompute && n >= 1024 && (nseg == 1 || ((uint64_t)n * W * 64 <= tab_max_bytes && nseg <= (size_t)MSM_MAX_PIECES));
     // a rank of an N-way row split touches windows [floor(W r / N), ceil(W (r + 1) / N)) only (bbgpu_set_table_share)
     const int twb = (int)((int64_t)W * g_ctx.share_rank / g_ctx.share_world);
     const int twe = (int)(((int64_t)W * (g_ctx.share_rank + 1) + g_ctx.share_world - 1) / g_ctx.share_world);
@@ -493,7 +496,7 @@ int split_pieces(const SrsEntry& e, size_t off, size_t n, PointPiece* out, int c
     }
     return cnt;
 }
-constexpr int MAX_POINT_PIECES = 2 * MSM_MAX_PIECES;
+constexpr int MAX_POINT_PIECES = MSM_MAX_PIECES;
 
 bool others_pending(const MsmSlot* a, const MsmSlot* b = nullptr)
 {

@@ -645,6 +645,51 @@ def test_msm_beyond_one_table_segment(gpu, oracle, golden):
     gpu.srs_release(h)
 
 
+def test_msm_pieces_against_the_oracle(gpu, oracle, msm_small):
+    """the piece machinery of the large MSMs (one window table per segment, pieces dealt to the ticket's slot and a helper, piece sums added on the
+    host) at sizes the ORACLE checks: BBGPU_TABLE_SEG_POINTS cuts a 10,000-point SRS into 10, 4 and 63 segments (1,000 / 2,504 / 160 points) --
+    prefixes, sub-slices that start and end inside segments, batches, window sub-ranges, skewed scalars, three compound tickets in flight (the later
+    ones find fewer free helper slots, down to all pieces on one slot), the host-pointer entries"""
+    import os
+    import torch
+    from barretenberg_amd import BbGpuError
+    g, srs, table, scalars = msm_small
+    n_all = 10000
+    one = oracle.const(FR, "one")
+    rng = np.random.default_rng(5)
+    try:
+        for seg in (1000, 3000, 160):
+            os.environ["BBGPU_TABLE_SEG_POINTS"] = str(seg)
+            tab = aligned_copy(table[:2 * n_all])  # its own address: a fresh registration under this segment size
+            h = gpu.srs_register(tab)
+            d = torch.from_numpy(aligned_copy(scalars[:n_all]).view(np.int64)).cuda()
+            cases = [(0, n_all), (0, seg), (0, seg + 1), (seg - 1, 2), (seg // 2, 2 * seg + 7), (3, n_all - 3), (n_all - 5, 5), (2 * seg, seg)]
+            for off, n in cases:
+                want = oracle.msm_affine(aligned_copy(scalars[:n]), aligned_copy(table[2 * off:2 * (off + n)]), n)
+                got = gpu.msm_device(h, d.data_ptr(), n, offset=off)
+                assert np.array_equal(got[:8], want[:8]), (seg, off, n)
+                assert np.array_equal(gpu.pippenger(aligned_copy(scalars[:n]), tab[2 * off:], n)[:8], want[:8]), ("host", seg, off, n)
+            if gpu.srs_has_window_tables(h):
+                W = gpu.srs_num_windows(h, n_all)
+                full = gpu.msm_device(h, d.data_ptr(), n_all)
+                parts = [gpu.msm_device(h, d.data_ptr(), n_all, window_begin=a, window_end=b) for a, b in ((0, W // 3), (W // 3, W - 1), (W - 1, W))]
+                assert np.array_equal(gpu.g1_sum(np.stack(parts)), full), seg
+                sets = [scalars[:n_all], np.tile(scalars[7], (n_all, 1)), np.stack([(np.zeros(4, dtype=np.uint64), one)[i] for i in rng.integers(0, 2, n_all)])]
+                dev = [torch.from_numpy(aligned_copy(a).view(np.int64)).cuda() for a in sets]
+                single = [gpu.msm_device(h, x.data_ptr(), n_all) for x in dev]
+                for k, a in enumerate(sets):
+                    assert np.array_equal(single[k][:8], oracle.msm_affine(aligned_copy(a), tab, n_all)[:8]), (seg, k)
+                got = gpu.msm_batch_wait(gpu.msm_device_batch_async(h, [x.data_ptr() for x in dev], n_all))
+                for k in range(3):
+                    assert np.array_equal(got[k], single[k]), (seg, "batch", k)
+                tickets = [gpu.msm_device_async(h, dev[k % 3].data_ptr(), n_all) for k in range(3)]  # compound tickets: the later ones find fewer free helpers
+                for k, t in enumerate(tickets):
+                    assert np.array_equal(gpu.msm_wait(t), single[k % 3]), (seg, "in flight", k)
+            gpu.srs_release(h)
+    finally:
+        del os.environ["BBGPU_TABLE_SEG_POINTS"]
+
+
 def test_msm_skewed_scalars_full_size(gpu, oracle, golden):
     """the skewed scalar sets (every scalar equal, {0, 1, -1}, values below 200: bench.skewed_scalars) at the FULL 2^20 size -- the
     heavy-bucket merge path at the size the headline is quoted on -- against the reference's points for the same vectors"""
