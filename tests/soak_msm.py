@@ -6,7 +6,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from barretenberg_amd import BbGpu
+from barretenberg_amd import BbGpu, BbGpuError
 from oracle.pyoracle import FR, Oracle, aligned_copy, build
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -65,17 +65,28 @@ while time.time() < t2:
     elif kind == 2:
         sc[:] = pool[int(rng.integers(0, N))]
     tab = aligned_copy(table[:2 * n])
+    # round 4: half of the tables are cut into several window-table segments (testing knob; the MSMs over them run as pieces on the ticket's slot
+    # and a helper slot), the one-call result itself is then checked against the oracle
+    segmented = rng.integers(0, 2) == 0
+    if segmented:
+        os.environ["BBGPU_TABLE_SEG_POINTS"] = str(int(rng.integers(max(64, n // 60), n)))
     h = G.srs_register(tab)
+    os.environ.pop("BBGPU_TABLE_SEG_POINTS", None)
     d = torch.from_numpy(aligned_copy(sc).view(np.int64)).cuda()
     full = G.msm_device(h, d.data_ptr(), n)
     W = G.srs_num_windows(h, n)
     Nn = int(rng.integers(1, 9))
-    tickets = [G.msm_device_buckets_async(h, d.data_ptr(), n, r, Nn) for r in range(min(Nn, 4))]
-    parts = [G.msm_wait(t) for t in tickets] + [G.msm_wait(G.msm_device_buckets_async(h, d.data_ptr(), n, r, Nn)) for r in range(4, Nn)]
-    okb = np.array_equal(G.g1_sum(np.stack(parts)), full)
-    cuts = [W * n * r // Nn for r in range(Nn + 1)]
-    parts = [G.msm_wait(G.msm_device_rows_async(h, d.data_ptr(), n, a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
-    okr = np.array_equal(G.g1_sum(np.stack(parts)), full)
+    try:
+        tickets = [G.msm_device_buckets_async(h, d.data_ptr(), n, r, Nn) for r in range(min(Nn, 4))]
+        parts = [G.msm_wait(t) for t in tickets] + [G.msm_wait(G.msm_device_buckets_async(h, d.data_ptr(), n, r, Nn)) for r in range(4, Nn)]
+        okb = np.array_equal(G.g1_sum(np.stack(parts)), full)
+        cuts = [W * n * r // Nn for r in range(Nn + 1)]
+        parts = [G.msm_wait(G.msm_device_rows_async(h, d.data_ptr(), n, a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
+        okr = np.array_equal(G.g1_sum(np.stack(parts)), full)
+    except BbGpuError:  # row / bucket shares are defined on one table segment
+        assert segmented
+        want = O.msm_affine(aligned_copy(sc), tab, n)
+        okb = okr = (int(full[7]) >> 63) == (int(want[7]) >> 63) and ((int(want[7]) >> 63) or np.array_equal(full[:8], want[:8]))
     # point-range shares (bench.py --shard points): ranges of the whole table, up to four in flight (the throughput choices of msm_issue_batch)
     pc = [n * r // Nn for r in range(Nn + 1)]
     tickets, parts = [], []
@@ -93,6 +104,35 @@ while time.time() < t2:
     G.srs_release(h)
 print("share splits: %d cases (bucket, row and point-range shares, 1..8 ranks), %d mismatches" % (share_cases, share_bad), flush=True)
 bad += share_bad
+
+# concurrent callers (round 4): four host threads on the host-pointer entries (MSM + transform), results against precomputed oracle answers
+import threading
+th_sizes = [4096, 1000, 10000, 257]
+th_sc = [aligned_copy(pool[rng.permutation(N)[:n]]) for n in th_sizes]
+th_want = [O.msm_affine(sc, table, n) for sc, n in zip(th_sc, th_sizes)]
+th_co = [O.random_scalars(900 + k, 1 << (9 + k)) for k in range(4)]
+th_ntt = [O.ntt(c, "coset_fft") for c in th_co]
+th_bad, th_calls = [], [0] * 4
+t3 = time.time() + budget / 6
+
+
+def hammer(i):
+    while time.time() < t3:
+        got = G.pippenger(th_sc[i], table, th_sizes[i])
+        if not np.array_equal(got[:8], th_want[i][:8]):
+            th_bad.append(("msm", i))
+        if not np.array_equal(G.coset_fft(th_co[i].copy()), th_ntt[i]):
+            th_bad.append(("ntt", i))
+        th_calls[i] += 2
+
+
+ths = [threading.Thread(target=hammer, args=(i,)) for i in range(4)]
+for t in ths:
+    t.start()
+for t in ths:
+    t.join()
+print("concurrent callers: %d calls from 4 threads, %d mismatches" % (sum(th_calls), len(th_bad)), flush=True)
+bad += len(th_bad)
 
 # pipelined: 4 different scalar vectors, two and three in flight, against their one-at-a-time results, at 2^15 and 2^20
 for lg in (15, 20):
