@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag>        (tag = r02 ...; outputs land in gpurun_out/prof_<tag>/, summaries are copied by hand)
 # Counter passes carry --pmc only (no tracing domains), one counter group per pass, as MI355X_MICROARCH.md prescribes.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -44,6 +44,9 @@ python tools/host_finish_cost.py > $OUT/host_finish_cost.txt 2>&1
 python tools/share_ab.py 8 4 2 > $OUT/share_ab.txt 2>&1
 python tools/point_share_ab.py 8 4 2 > $OUT/point_share_ab.txt 2>&1
 python tools/issue_cost.py > $OUT/issue_cost.txt 2>&1
+python tools/host_step_cost.py > $OUT/host_step_cost.txt 2>&1
+python tools/msm_big.py 20 21 22 24 > $OUT/msm_big.txt 2>&1
+for g in 1048576 2097152; do python tools/plonk_bench.py --gates $g --reps 5 --no-reference; done > $OUT/plonk_big.txt 2>&1
 ( cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq8 -- python3 $ROOT/tools/share_run.py points 8 2 > $OUT/sq8.log 2>&1 ) && python tools/pmc_sq_summary.py $OUT/sq8 $OUT/${TAG}_pmc_sq_share8_points.json > /dev/null; rm -rf $OUT/sq8
 python tools/skewed_stages.py > $OUT/skewed_stages.txt 2>&1
 python tools/boundary_ab.py > $OUT/boundary_ab.txt 2>&1
