@@ -6,7 +6,11 @@
 #include <cstring>
 #include <vector>
 
+#include <mutex>
+#include <thread>
+
 #include "../../barretenberg_amd/csrc/host_small.hpp"
+#include "../../barretenberg_amd/csrc/host_fallback.hpp"
 #include "../../barretenberg_amd/csrc/host_g2.hpp"
 #include "../../barretenberg_amd/csrc/keccak.hpp"
 #define BBGPU_COPY_POOL_TEST_DELAY 1 // helpers of a (re)started pool get to run before the first job is posted: the window of the round-3 bug
@@ -150,6 +154,80 @@ int main()
         memset(small_src, 7, sizeof small_src);
         pool.copy(small_dst, small_src, sizeof small_src); // below the parallel threshold: the caller's thread alone
         CHECK(!memcmp(small_dst, small_src, sizeof small_src), "copy pool: small copy");
+    }
+    // ---- round 4: the staging copies are entered from several threads (the resident prover's uploads beside another thread's transform) and take the
+    //      library mutex themselves (capi.hip host_to_device / device_to_host_sync); the single-producer pool behind such a guard, two threads at once
+    {
+        CopyPool pool;
+        std::mutex guard; // stands for capi.hip's g_mu
+        int bad[2] = { 0, 0 };
+        auto worker = [&](int id) {
+            for (int rep = 0; rep < 12; rep++) {
+                const size_t bytes = ((size_t)1 << 20) + 8192 * (size_t)(rep + id) + (size_t)(id ? 77 : 0);
+                std::vector<unsigned char> src(bytes), dst(bytes, 0);
+                for (size_t i = 0; i < bytes; i += 53) src[i] = (unsigned char)(i * 7 + (size_t)rep + (size_t)id);
+                {
+                    std::lock_guard<std::mutex> lk(guard);
+                    pool.copy(dst.data(), src.data(), bytes);
+                }
+                if (memcmp(dst.data(), src.data(), bytes)) bad[id]++;
+            }
+        };
+        std::thread a(worker, 0), b(worker, 1);
+        a.join();
+        b.join();
+        CHECK(bad[0] == 0 && bad[1] == 0, "guarded copy pool from two threads: %d / %d bad copies", bad[0], bad[1]);
+    }
+    // ---- round 4: the shim's host answers (host_fallback.hpp) against the oracle: MSM at sizes on both sides of its thresholds, the transform family,
+    //      evaluate and the synthetic division (threads inside: run under the sanitizers like everything else here)
+    {
+        const size_t M = 300;
+        std::vector<uint64_t> srs2(8 * M), tab2(16 * M), sc2(4 * M);
+        orc_make_srs(x, M, srs2.data());
+        orc_generate_point_table(srs2.data(), tab2.data(), M);
+        orc_random_scalars(321, M, sc2.data());
+        for (size_t n : { (size_t)33, (size_t)64, (size_t)255, M }) {
+            uint64_t want[12], wn[12], got[12];
+            orc_pippenger(sc2.data(), tab2.data(), n, 0, want);
+            orc_g1_normalize(want, wn);
+            g1_to_normalised(msm_pippenger(sc2.data(), tab2.data(), n, 16), got);
+            CHECK(!memcmp(wn, got, 64), "msm_pippenger n %zu", n);
+            g1_to_normalised(msm_pippenger(sc2.data(), srs2.data(), n, 8), got);
+            CHECK(!memcmp(wn, got, 64), "msm_pippenger (plain table) n %zu", n);
+        }
+        uint64_t cst[4];
+        orc_random_scalars(55, 1, cst);
+        for (int lg : { 1, 2, 5, 9 }) {
+            const size_t n = (size_t)1 << lg;
+            std::vector<uint64_t> in(4 * n), a(4 * n), b(4 * n);
+            orc_random_scalars(400 + (uint64_t)lg, n, in.data());
+            for (int kind = 0; kind < 7; kind++) {
+                a = in;
+                b = in;
+                orc_ntt(a.data(), n, kind, cst);
+                ntt_radix2(b.data(), lg, kind, cst);
+                CHECK(a == b, "ntt_radix2 lg %d kind %d", lg, kind);
+            }
+            uint64_t z[4], want[4];
+            orc_random_scalars(77 + (uint64_t)lg, 1, z);
+            orc_evaluate(in.data(), z, n, want);
+            Fr zz;
+            memcpy(zz.d, z, 32);
+            const Fr got = poly_evaluate(in.data(), n, zz);
+            CHECK(!memcmp(got.d, want, 32), "poly_evaluate lg %d", lg);
+            std::vector<uint64_t> q(4 * n);
+            const Fr fz = kate_opening(in.data(), q.data(), n, zz);
+            CHECK(!memcmp(fz.d, want, 32), "kate_opening F(z) lg %d", lg);
+            // (X - z) Q(X) + F(z) = F(X) at another point
+            uint64_t y[4], fy[4], qy[4];
+            orc_random_scalars(99 + (uint64_t)lg, 1, y);
+            orc_evaluate(in.data(), y, n, fy);
+            orc_evaluate(q.data(), y, n, qy);
+            Fr Y, QY, FY;
+            memcpy(Y.d, y, 32); memcpy(QY.d, qy, 32); memcpy(FY.d, fy, 32);
+            const Fr lhs = fr_add(fr_mul(fr_sub(Y, fr_mul(zz, fr_one())), QY), fz);
+            CHECK(!memcmp(lhs.d, FY.d, 32), "kate_opening identity lg %d", lg);
+        }
     }
     printf(fails ? "FAILED %d\n" : "ALL OK %d\n", fails);
     return fails ? 1 : 0;
