@@ -52,6 +52,7 @@ struct MsmSlot {
     bool append = false; // set by the caller before an issue: add a piece to the MSM already issued on this slot instead of starting a new one
     int helper = -1;     // capi.hip: a second slot (own stream and workspace) that carries every other piece of this ticket, or -1
     bool is_helper = false; // this slot is pending as the helper of another ticket: collected through its owner only
+    bool reserved = false;  // capi.hip: a synchronous entry point is cycling its jobs / ranges through this slot: not to be taken as a helper meanwhile
     hipStream_t stream = nullptr; // the slot's own stream (used when the caller passes none)
     hipEvent_t done = nullptr;
     hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };

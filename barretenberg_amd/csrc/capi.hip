@@ -466,6 +466,21 @@ int free_slots(int* out, int want)
         if (!g_ctx.slot[k].pending) out[got++] = k;
     return got;
 }
+// the slots a synchronous entry point cycles its jobs / ranges through: marked for the duration of the call, so that a multi-piece job on one of
+// them does not take the other as its helper (it is free NOW and about to carry the next job)
+struct SlotReservation {
+    int a, b;
+    SlotReservation(const int* sl, int n) : a(n > 0 ? sl[0] : -1), b(n > 1 ? sl[1] : -1)
+    {
+        if (a >= 0) g_ctx.slot[a].reserved = true;
+        if (b >= 0) g_ctx.slot[b].reserved = true;
+    }
+    ~SlotReservation()
+    {
+        if (a >= 0) g_ctx.slot[a].reserved = false;
+        if (b >= 0) g_ctx.slot[b].reserved = false;
+    }
+};
 int ensure_slot_stream(MsmSlot& S)
 {
     if (!S.stream) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
@@ -547,7 +562,7 @@ int issue_ticket(int t, const SrsEntry& e, size_t off, const uint64_t* const* d_
         if (t < 2) order[cnt++] = t ^ 1; // the pair the two-deep pipeline of large MSMs uses
         for (int k = Context::NSLOT - 1; k >= 2; --k) order[cnt++] = k; // from the top: the low ones are what the next tickets take
         for (int k = 0; k < cnt && h < 0; k++)
-            if (order[k] != t && !g_ctx.slot[order[k]].pending) h = order[k];
+            if (order[k] != t && !g_ctx.slot[order[k]].pending && !g_ctx.slot[order[k]].reserved) h = order[k];
     }
     MsmSlot* H = h >= 0 ? &g_ctx.slot[h] : nullptr;
     if (H) {
@@ -696,6 +711,7 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
     }
     for (int k = 0; k < ns; k++)
         if (int rc = ensure_slot_stream(g_ctx.slot[sl[k]])) return rc;
+    SlotReservation reserve(sl, ns);
     // A table that was never registered and is too small to be an SRS (the verifier's ~20 freshly built points,
     // verifier.cpp:359-363) is used once and forgotten: caching it by address would both leak device memory per call and
     // serve stale points when the caller's vector is freed and its address reused.  Larger unknown tables are taken to be a
@@ -1509,6 +1525,7 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
     if ((rc = ensure_init()) != BBGPU_OK) return rc;
     for (int k = 0; k < 2; k++)
         if ((rc = ensure_slot_stream(g_ctx.slot[sl[k]])) != BBGPU_OK) return rc;
+    SlotReservation reserve(sl, 2); // a job that straddles two table segments takes its helper elsewhere (or none)
     // Two-slot pipeline over the jobs of a prover round (3/1/3/2 MSMs, prover.cpp:65-122,650-658): job i+1's scalars
     // cross PCIe and its kernels are enqueued while job i's bucket-reduction tail and host finish run.
     uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };

@@ -669,6 +669,15 @@ def test_msm_pieces_against_the_oracle(gpu, oracle, msm_small):
                 got = gpu.msm_device(h, d.data_ptr(), n, offset=off)
                 assert np.array_equal(got[:8], want[:8]), (seg, off, n)
                 assert np.array_equal(gpu.pippenger(aligned_copy(scalars[:n]), tab[2 * off:], n)[:8], want[:8]), ("host", seg, off, n)
+            # the host-pointer batch (batched_scalar_multiplications) over sub-slices that straddle segment boundaries: its two-slot pipeline keeps its slots to itself,
+            # a straddling job takes its helper elsewhere
+            nb = min(2 * seg, 1500)
+            offs = [max(0, seg - 5), 3, 2 * seg - nb // 2, seg // 2]
+            jobs = [(tab[2 * o:], aligned_copy(scalars[k:k + nb]), nb) for k, o in enumerate(offs)]
+            outs = gpu.batched_scalar_multiplications(jobs)
+            for k, o in enumerate(offs):
+                want = oracle.msm_affine(aligned_copy(scalars[k:k + nb]), aligned_copy(table[2 * o:2 * (o + nb)]), nb)
+                assert np.array_equal(outs[k][:8], want[:8]), ("host batch", seg, k, o)
             if gpu.srs_has_window_tables(h):
                 W = gpu.srs_num_windows(h, n_all)
                 full = gpu.msm_device(h, d.data_ptr(), n_all)
