@@ -773,14 +773,22 @@ int mul2c(uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n, c
     return BBGPU_OK;
 }
 
-// scratch layout of a scan over n elements: tpart, bpart, bcarry, plus the nested single-block scan's own tpart/bpart
-size_t scan_scratch_bytes(size_t n)
+// scratch layout of a scan over n elements: tpart, bpart, bcarry, plus the nested single-block scan's own tpart/bpart -- and, above 2^22 elements,
+// where the scan over the block totals is a two-level scan of its own, that scan's scratch behind it
+static size_t scan_scratch_own(size_t n)
 {
     const size_t nt = (n + RUN - 1) / RUN, nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    return (nt + 2 * nb + (nb + RUN - 1) / RUN + 8) * 32 + 1024;
+    return (((nt + 2 * nb + (nb + RUN - 1) / RUN + 8) * 32 + 1024) + 255) & ~(size_t)255;
+}
+size_t scan_scratch_bytes(size_t n)
+{
+    const size_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    return scan_scratch_own(n) + (nb > (size_t)SCAN_BLOCK ? scan_scratch_bytes(nb) : 0);
 }
 
-// MODE 0 product scan (z ignored) / MODE 1 Horner suffix sums with multiplier z.  n <= 2^22 (one nested level).
+// MODE 0 product scan (z ignored) / MODE 1 Horner suffix sums with multiplier z.  Three phases: runs of RUN per thread and a scan of the thread partials
+// in LDS (phase 1), a scan over the block totals, the carry pass (phase 3).  The scan over the block totals is one workgroup up to 2^22 elements
+// and the same three phases again above (round 4: n up to 2^28, the transforms' limit; the prover's L_1 scan is 2n).
 // Up to two independent scans of the same mode share the launches (ScanJob[2]; the second may have n = 0).
 static void scan_fill(int mode, const ScanJob& J, uint8_t* base, ScanArgs& A, ScanArgs& B)
 {
@@ -827,21 +835,31 @@ static void scan_fill(int mode, const ScanJob& J, uint8_t* base, ScanArgs& A, Sc
         B.zpow[9] = host::limbs_m261(zbr);
     }
 }
+static int scan_pair_at(int mode, const ScanJob* jobs, int count, uint8_t* base, hipStream_t st);
 int scan_pair(int mode, const ScanJob* jobs, int count, Scratch& S, hipStream_t st)
 {
     if (count < 1 || count > 2) return BBGPU_ERR_ARG;
-    size_t off[3] = { 0, 0, 0 }, nbmax = 0;
+    size_t total = 0;
     for (int j = 0; j < count; j++) {
-        if (jobs[j].n > ((size_t)SCAN_BLOCK * SCAN_BLOCK)) {
-            set_error("scan of %zu elements: at most 2^22", jobs[j].n);
+        if (jobs[j].n > ((size_t)1 << 28)) {
+            set_error("scan of %zu elements: at most 2^28", jobs[j].n);
             return BBGPU_ERR_SIZE;
         }
-        off[j + 1] = off[j] + ((scan_scratch_bytes(jobs[j].n) + 255) & ~(size_t)255);
+        total += scan_scratch_bytes(jobs[j].n);
+    }
+    int rc = S.ensure(total + 64); // the whole nest at once: the workspace must not move under the launches of an outer level
+    if (rc) return rc;
+    return scan_pair_at(mode, jobs, count, S.base, st);
+}
+static int scan_pair_at(int mode, const ScanJob* jobs, int count, uint8_t* base, hipStream_t st)
+{
+    size_t off[3] = { 0, 0, 0 }, nbmax = 0;
+    for (int j = 0; j < count; j++) {
+        off[j + 1] = off[j] + scan_scratch_bytes(jobs[j].n);
         nbmax = std::max(nbmax, (jobs[j].n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     }
     if (nbmax == 0) return BBGPU_OK;
-    int rc = S.ensure(off[count] + 64);
-    if (rc) return rc;
+    struct { uint8_t* base; } S{ base };
     ScanArgs A[2], B[2];
     A[1] = ScanArgs{};
     B[1] = ScanArgs{};
@@ -868,6 +886,40 @@ int scan_pair(int mode, const ScanJob* jobs, int count, Scratch& S, hipStream_t 
         } else {
             k_scan_phase1<1><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
             k_scan_phase3<1><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
+        }
+    } else
+    if (nbmax > (size_t)SCAN_BLOCK) {
+        // more block totals than one workgroup scans: the scan over them (exclusive, same direction; Horner: multiplier z^SCAN_BLOCK) is a scan of this
+        // kind itself, run on the scratch behind this level's; its grand total lands where the one-workgroup form leaves it (B.bpart)
+        if (mode == 0) k_scan_phase1<0><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
+        else k_scan_phase1<1><<<g1, SCAN_T, 0, st>>>(A[0], A[1]);
+        for (int j = 0; j < count; j++) {
+            const size_t nb = (jobs[j].n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+            if (nb == 0) continue;
+            if (nb <= (size_t)SCAN_BLOCK) { // the shorter of two jobs may still fit a workgroup: the one-block form, alone in its launch
+                ScanArgs none{};
+                if (mode == 0) {
+                    k_scan_phase1<0><<<dim3(1, 1), SCAN_T, 0, st>>>(B[j], none);
+                    k_scan_phase3<0><<<dim3(1, 1), SCAN_T, 0, st>>>(B[j], none);
+                } else {
+                    k_scan_phase1<1><<<dim3(1, 1), SCAN_T, 0, st>>>(B[j], none);
+                    k_scan_phase3<1><<<dim3(1, 1), SCAN_T, 0, st>>>(B[j], none);
+                }
+                continue;
+            }
+            ScanJob I{};
+            I.in = (const uint64_t*)A[j].bpart;
+            I.out = (uint64_t*)A[j].bcarry;
+            I.n = nb;
+            I.reverse = jobs[j].reverse;
+            I.inclusive = false;
+            I.d_total = (uint64_t*)B[j].bpart;
+            if (mode == 1) I.z = host::fr_pow(jobs[j].z, SCAN_BLOCK);
+            if (int rc = scan_pair_at(mode, &I, 1, S.base + off[j] + scan_scratch_own(jobs[j].n), st)) return rc;
+        }
+        if (any_out) {
+            if (mode == 0) k_scan_phase3<0><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
+            else k_scan_phase3<1><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
         }
     } else
     if (mode == 0) {
