@@ -116,10 +116,11 @@ def test_domain_helpers_vs_oracle(gpu, torch, oracle, log2n):
 
 
 # ------------------------------------------------------------------ size-independent properties at BASELINE size ---------
-def test_helpers_properties_2_20(gpu, torch, oracle):
-    """n = 2^20: a^-1 * a = 1 everywhere; (X - z) W(X) + F(z) = F(X) checked at a random point through evaluate;
-    inclusive prefix product's last element = exclusive suffix product's first * a_0; evaluate is linear"""
-    n = 1 << 20
+@pytest.mark.parametrize("n", [1 << 20, (1 << 22) + 5, 1 << 23])
+def test_helpers_properties_2_20(gpu, torch, oracle, n):
+    """n = 2^20, and beyond 2^22 where the scan over the block totals is a three-phase scan of its own (round 4; 2^22 + 5: the inner scan has two
+    workgroups, the second nearly empty): a^-1 * a = 1 everywhere; (X - z) W(X) + F(z) = F(X) checked at a random point through evaluate;
+    inclusive prefix product's last element = exclusive suffix product's first * a_0; a prefix of the running product against the big-integer oracle"""
     v = oracle.random_scalars(0xB16, n)
     z, x = oracle.random_scalars(0xB17, 2)
     dv = dev(torch, v)

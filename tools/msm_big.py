@@ -27,6 +27,9 @@ for lg in lgs:
     dt = float(np.median(ts))
     # two calls in flight (what a prover's consecutive commitments look like)
     reps = 6
+    for _ in range(2):  # the slots the second ticket and its helper land on allocate their workspaces on first use: not in the timed loop
+        tw = [G.msm_device_async(h, d.data_ptr(), n), G.msm_device_async(h, d.data_ptr(), n)]
+        for t in tw: G.msm_wait(t)
     t0 = time.perf_counter()
     tk = [G.msm_device_async(h, d.data_ptr(), n)]
     for _ in range(reps - 1):
