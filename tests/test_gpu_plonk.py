@@ -146,6 +146,16 @@ def test_helpers_properties_2_20(gpu, torch, oracle, n):
     # chunk-wise check of the whole-vector product against the big-integer oracle on a sub-range
     m = 3000
     assert P.plain(host(pre[m - 1:m]))[0] == P.plain(P.product_scan(v[:m], False, True)[m - 1:m])[0]
+    # the recurrences themselves where carries cross a level: run, workgroup (2048), the inner scan's workgroup (2048 x 2048) and ragged positions
+    hp, hs, hw = host(pre), host(suf), host(w)
+    ks = sorted({k for k in (1, 7, 8, 9, 2047, 2048, 2049, 4095, 4096, (1 << 20) - 1, 1 << 20, (1 << 22) - 1, 1 << 22, (1 << 22) + 1, (1 << 22) + 4,
+                             3 * (1 << 21) + 123, n - 2, n - 1) if 1 <= k < n})
+    pv, pp, ps, pw = P.plain(v[ks]), P.plain(hp[ks]), P.plain(hs[ks]), P.plain(hw[ks])
+    pp1, ps1, pw1 = P.plain(hp[[k - 1 for k in ks]]), P.plain(hs[[k - 1 for k in ks]]), P.plain(hw[[k - 1 for k in ks]])
+    for i, k in enumerate(ks):
+        assert pp[i] == pp1[i] * pv[i] % FR_MODULUS, ("prefix", n, k)           # inclusive prefix: pre[k] = pre[k-1] v[k]
+        assert ps1[i] == ps[i] * pv[i] % FR_MODULUS, ("suffix", n, k)           # exclusive suffix: suf[k-1] = suf[k] v[k]
+        assert pw1[i] == (pv[i] + zp * pw[i]) % FR_MODULUS, ("kate", n, k)      # W[k-1] = F[k] + z W[k]
 
 
 # ------------------------------------------------------------------ the resident prover ----------------------------------
