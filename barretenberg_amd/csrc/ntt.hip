@@ -383,8 +383,16 @@ __device__ __forceinline__ Radix4Out radix4_lazy(const FrS& x0, const FrS& x1, c
 #endif
 template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT_OCC_ATTR ntt_pass_fused_kernel(NttPassArgs A)
 {
-    extern __shared__ uint32_t lds[]; // [9][cols * S]
-    const uint32_t S = 1u << A.log_s, cols = A.cols, E = cols * S, quarter = S >> 2, ngr = cols * quarter;
+    extern __shared__ uint32_t lds[]; // [9][E]
+    // The plane stride is the TILE size of this instantiation (four elements per thread), a compile-time constant: the nine plane offsets of every LDS
+    // access then sit in the instruction's offset field instead of costing a v_add each (round 4: ~30 of a stage pair's 1,049 VALU instructions);
+    // a launch whose sub-transforms fill less than a tile (n below the tile size) uses the front of every plane.
+#ifdef BBGPU_NTT_RUNTIME_STRIDE
+    const uint32_t E = A.cols << A.log_s;
+#else
+    constexpr uint32_t E = (uint32_t)THREADS * 4u;
+#endif
+    const uint32_t S = 1u << A.log_s, cols = A.cols, quarter = S >> 2, ngr = cols * quarter;
     uint32_t bid = blockIdx.x;
     if (A.xcd_remap && (gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const uint32_t b0 = bid * cols;
@@ -810,7 +818,7 @@ uint32_t ntt_tile_elems(int log2n)
 template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st)
 {
     const uint32_t S = 1u << A.log_s, blocks = (1u << A.log_b) / A.cols;
-    const size_t lds = (size_t)A.cols * S * NL * 4;
+    const size_t lds = (size_t)A.cols * S * NL * 4; // the unfused kernel; the fused instantiations take their whole tile (constant plane stride)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
@@ -824,11 +832,11 @@ template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st
         NttPassArgs B = A;
         B.store_b_fast = (A.out_sb == 1 && A.cols > 1) ? 1u : 0u;
         if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) // double tile: one workgroup of 1024 threads per CU (144 KiB of LDS), rows twice as wide
-            ntt_pass_fused_kernel<FLAGS, 2 * NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), 2 * NTT_THREADS, lds, st>>>(B);
+            ntt_pass_fused_kernel<FLAGS, 2 * NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), 2 * NTT_THREADS, (size_t)8 * NTT_THREADS * NL * 4, st>>>(B);
         else if (A.half_tile && (size_t)A.cols * S <= (size_t)NTT_LDS_ELEMS / 2) // half tile: four workgroups of 256 threads per CU
-            ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS / 2, lds, st>>>(B);
+            ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS / 2, (size_t)2 * NTT_THREADS * NL * 4, st>>>(B);
         else
-            ntt_pass_fused_kernel<FLAGS, NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(B);
+            ntt_pass_fused_kernel<FLAGS, NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, (size_t)4 * NTT_THREADS * NL * 4, st>>>(B);
     } else {
         if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) return hipErrorInvalidValue; // the double tile exists in the fused kernel only
         ntt_pass_kernel<FLAGS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(A);
