@@ -1062,6 +1062,11 @@ __device__ __forceinline__ Xyzz shfl_down_xyzz(const Xyzz& p, uint32_t off)
 // The tail kernels are held to 128 VGPRs (amdgpu_waves_per_eu(4, 4), ~32 registers spilled): at the 143 they would otherwise
 // take, their waves do not fit beside the three 128-VGPR accumulation waves per SIMD of the next MSM and the whole tail queued
 // behind it (rocprof timeline: merge 0.5 ms and heavy-merge 0.58 ms in the two-deep pipeline against 0.05 ms alone).
+// TAIL_OCC: the register cap of the tail kernels (see above).  -DBBGPU_TAIL_WAVES=k sets another occupancy target for A/B builds (2: up to 256 VGPRs, no spills).
+#ifndef BBGPU_TAIL_WAVES
+#define BBGPU_TAIL_WAVES 4
+#endif
+#define TAIL_OCC __attribute__((amdgpu_waves_per_eu(BBGPU_TAIL_WAVES, BBGPU_TAIL_WAVES)))
 constexpr int FOLD_T = 256;
 constexpr int FOLD_LDS_WORDS = (FOLD_T / 2) * RAW_WORDS;
 __device__ __forceinline__ void wg_tree_sum(Xyzz& acc, uint32_t* sh, uint32_t T, uint32_t t)
@@ -1093,7 +1098,7 @@ __device__ __forceinline__ void wg_tree_sum(Xyzz& acc, uint32_t* sh, uint32_t T,
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+__global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_merge_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                               uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t bucket_begin, uint32_t total_buckets,
                                                               uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logG)
 {
@@ -1136,7 +1141,7 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
 // -- skewed digits: every scalar equal puts 2^20 entries, ~13 k partials, into each of 15 buckets -- : the gridDim.x workgroups are dealt
 // K = gridDim.x / count to a bucket, each sums a slice of its partials into a raw partial of its own (hpart), and the LAST of a bucket's
 // workgroups to arrive (agent-scope fences around an arrival counter) adds the K slices up (round 3: 0.45 -> ~0.1 ms for that case).
-__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+__global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t ch, uint32_t* __restrict__ hpart)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
@@ -1212,7 +1217,7 @@ __device__ __forceinline__ uint32_t insert_one_bit(uint32_t m, uint32_t k)
 
 // Row sums R[hi] = sum_lo B[hi][lo] (blockIdx.x < H) and column sums C[lo] = sum_hi B[hi][lo] (blockIdx.x >= H) of the
 // H x L bucket matrix of group blockIdx.y; blockDim.x = max(H, L).
-__global__ void __launch_bounds__(FOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
+__global__ void __launch_bounds__(FOLD_T) TAIL_OCC msm_rowcol_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
                                                           uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
@@ -1242,7 +1247,7 @@ __global__ void __launch_bounds__(FOLD_T) __attribute__((amdgpu_waves_per_eu(4, 
 // Job 0: Z = sum R; job 1 + k: TR_k = sum of the R_hi whose bit k is set; job 1 + hbits + k: TC_k likewise over C.  Each job is
 // one workgroup; results go straight into the 64-slot export array in the reference's Montgomery form (slot 0 = Z,
 // 1 + k = TR_k, 32 + k = TC_k; the array is zeroed = infinity beforehand).
-__global__ void __launch_bounds__(FOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_final_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(FOLD_T) TAIL_OCC msm_final_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
                                                          uint32_t hbits, uint32_t lbits)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
@@ -1332,7 +1337,7 @@ __device__ __forceinline__ void quad_store8(uint32_t* dst8, const uint32_t (&w)[
 // word 9 l), the quads of a bucket are combined by a shuffle tree and quad 0 writes the bucket canonical, 8 words per lane.  The chain is
 // ~ceil(count / Q) + logQ quad additions of ~1,250 instructions: at 2^20 (4 partials per bucket, Q = 1) 3 quad additions instead of
 // 3 full ones, at 2^16 (9.5 partials, Q = 4) 4 instead of 6.
-__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_merge_quad_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
+__global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_merge_quad_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t bucket_begin, uint32_t total_buckets,
                                                                    uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logQ)
 {
@@ -1388,7 +1393,7 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
     }
 }
 
-__global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_quad_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
+__global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_rowcol_quad_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
                                                                   uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words, uint32_t r0, uint32_t rows)
 {
     // rows [r0, r0 + rows) of the H x L bucket matrix (all of them, or a bucket-range share's): blockIdx.x < rows sums row r0 + blockIdx.x,
@@ -1424,7 +1429,7 @@ __global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4,
 // lane-instructions against 4 x 1,350 for a quad): 3 dependent additions, every lane busy.  Step 2: one wave per row / column sums its
 // L / SEG (H / SEG) segment sums as 16 quads (<= 3 sequential + 4 tree levels).  2^16 buckets: 5.7 M + 4.5 M instructions for the same chain length.
 constexpr uint32_t ROWCOL_SEG = 4;
-__global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_rowcol_seg_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ segs, uint32_t H, uint32_t L,
+__global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_rowcol_seg_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ segs, uint32_t H, uint32_t L,
                                                                                                                 uint32_t* __restrict__ zero_out, uint32_t zero_words)
 {
     __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
@@ -1468,7 +1473,7 @@ __global__ void __launch_bounds__(MSM_THREADS) __attribute__((amdgpu_waves_per_e
     store_xyzz(o, acc);
     st32(segs + ((size_t)g * (row_lanes + col_lanes) + out) * 32, o);
 }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_segsum_quad_kernel(const uint32_t* __restrict__ segs, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc, uint32_t H, uint32_t L)
+__global__ void __launch_bounds__(64) TAIL_OCC msm_segsum_quad_kernel(const uint32_t* __restrict__ segs, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc, uint32_t H, uint32_t L)
 {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t g = blockIdx.y, t = threadIdx.x, l = t & 3, quad = t >> 2;
@@ -1490,7 +1495,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         quad_store8((row ? R + ((size_t)g * H + idx) * 32 : Cc + ((size_t)g * L + idx) * 32) + 8 * l, w);
     }
 }
-__global__ void __launch_bounds__(QFOLD_T) __attribute__((amdgpu_waves_per_eu(4, 4))) msm_final_quad_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_final_quad_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
                                                                  uint32_t hbits, uint32_t lbits)
 {
     __builtin_amdgcn_s_setprio(3);
