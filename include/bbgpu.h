@@ -109,8 +109,14 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
 int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
 /* Registration also builds, on the device, the pre-shifted window tables 2^(c w) * P_i (the reference's
  * generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129): W x n x 64 bytes (1 GiB at n = 2^20), so that
- * all digit windows share one bucket set.  On by default for 1024 <= n <= 2^20; bbgpu_set_precompute(0) turns it off for
- * tables registered afterwards.  Results are identical either way. */
+ * all digit windows share one bucket set.  On by default from 1024 points on; bbgpu_set_precompute(0) turns it off for
+ * tables registered afterwards.  Results are identical either way.
+ * The sorted entries of an MSM carry a 24-bit table row, i.e. one table serves 2^24 / W points (2^20 at 15 windows): a LARGER SRS keeps
+ * one table per segment of at most that many points (equal segments; 16 GiB of tables at 2^24 points, up to BBGPU_TABLE_MAX_BYTES = 64 GiB,
+ * beyond which -- or when the allocation fails -- the points stay resident without tables), and an MSM over it runs as one PIECE per
+ * segment it touches, dealt to the ticket's slot and a helper slot, the piece sums added on the host: the reference's own decomposition
+ * into point ranges per thread (scalar_multiplication.cpp:703-738).  2^21 / 2^22 / 2^24 points: 2.7 / 5.1 / 18.9 ms on one MI355X.
+ * Row- and bucket-range shares (below) are defined on ONE segment. */
 void bbgpu_set_precompute(int enabled);
 /* Multi-GPU: tables registered after this call keep only the digit windows that rank `rank` of `world` touches when the W x n (window,
  * point) rows are split evenly over the ranks (bbgpu_msm_g1_device_rows_async with rows [W n r / N, W n (r + 1) / N), or whole-window
@@ -188,7 +194,8 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs);
 int bbgpu_msm_num_windows(size_t n);
 int bbgpu_msm_g1_device(int srs_handle, size_t offset, const uint64_t* d_scalars, size_t n, int window_begin,
                         int window_end, uint64_t out[12], void* hip_stream);
-/* Asynchronous form: enqueue (returns a ticket >= 0, or a negative error) and collect later.  Up to eight MSMs may be in
+/* Asynchronous form: enqueue (returns a ticket >= 0, or a negative error) and collect later.  A ticket is waited for once, by one
+ * thread; the wait blocks outside the library's mutex, so other threads keep issuing and collecting meanwhile.  Up to eight MSMs may be in
  * flight; the bucket-reduction tail and host finish of one then overlap the sort/accumulate of the next (DESIGN_HISTORY.md 5), and
  * small latency-bound MSMs (a prover round's three commitments) run side by side.  With hip_stream == NULL each ticket runs
  * on its own internal stream.  An MSM enqueued while another is in flight is laid out for throughput instead of latency (longer
@@ -213,9 +220,10 @@ int bbgpu_srs_has_window_tables(int srs_handle); /* 1 / 0, < 0: unknown handle *
 int bbgpu_msm_g1_wait(int ticket, uint64_t out[12]);
 /* Whole-batch entry (the prover commits 3 / 1 / 3 / 2 polynomials per round over the same SRS,
  * prover.cpp:65-122,650-658): `jobs` (1..4) resident scalar vectors of n scalars each against points [offset, offset + n) of a
- * table registered WITH window tables, issued as ONE pass through the pipeline -- one bucket set per job in the shared sort /
- * accumulate / merge / reduction kernels -- so the batch pays one chain of launches and dependent additions, not `jobs`.
- * bbgpu_msm_g1_batch_wait writes jobs x 12 limbs (normalised).  Uses one of the eight tickets. */
+ * table registered WITH window tables, issued as ONE pass through the pipeline (per table segment touched) -- one bucket set per job in
+ * the shared sort / accumulate / merge / reduction kernels -- so the batch pays one chain of launches and dependent additions, not `jobs`.
+ * bbgpu_msm_g1_batch_wait writes jobs x 12 limbs (normalised).  Uses one of the eight tickets (and, over several segments, a free
+ * one as its helper). */
 int bbgpu_msm_g1_device_batch_async(int srs_handle, size_t offset, const uint64_t* const* d_scalars, int jobs, size_t n, void* hip_stream);
 int bbgpu_msm_g1_batch_wait(int ticket, uint64_t* out);
 /* out = sum of `count` normalised/Jacobian points (infinity flags honoured), normalised.  Host arithmetic. */
