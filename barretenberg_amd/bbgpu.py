@@ -385,7 +385,7 @@ class BbGpu:
 
     # ---- device self-test (known-answer entry points of the field / group layer) ---------------------------------------
     SELFTEST_FIELD_OPS = {"mul": 0, "sqr": 1, "add": 2, "sub": 3, "neg": 4, "mul_add": 5, "mul_sub": 6, "lazy_limbs": 7, "lazy_weak": 8,
-                          "lazy_value": 9, "reduce": 10, "sqr_lazy": 11, "zero_tests": 12}
+                          "lazy_value": 9, "reduce": 10, "sqr_lazy": 11, "zero_tests": 12, "mul_addhi": 13, "sqr_addhi": 14}
     SELFTEST_G1_OPS = {"madd": 0, "add": 1, "dbl": 2, "dbl_affine": 3, "madd_neg": 4, "quad_add": 5}
 
     def selftest_field(self, field, op, a, b):

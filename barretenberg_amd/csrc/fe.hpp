@@ -344,6 +344,59 @@ BB_HD void mul2_raw_inplace(const uint32_t (&a)[NL], const uint32_t (&b)[NL], ui
     for (int i = 0; i < NL; i++) c[i] = t[i];
 }
 
+// "addhi" forms (round 4): a <- REDC(a b) + e and out = REDC(a^2) + e, computed as REDC(a b + e 2^261) -- limb j of e is added to column j + 9 of the
+// double-width product, inside the carry chain the reduction runs anyway.  The sum comes out with EXACT limbs, so a difference such as
+// P = x2 ZZ1 - X1 of the mixed addition (e = K p - X1, limb-wise non-negative) costs nine additions of e's limbs instead of a separate
+// subtraction (18 instructions) and renormalisation (24), and X3 = R^2 - (PPP + 2 Q) needs no carry_full (27).  e may have any limbs below 2^32:
+// a column gains at most 2^32 against a head-room of 2^58 (9 (6 U^2) + 9 2^58 + carry < 2^64).
+template <class F> BB_HD void mul_addhi_raw_inplace(uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&e)[NL])
+{
+#if BBGPU_MONT_ASM
+    mul_addhi_raw_inplace_gfx950<F>(a, b, e);
+    return;
+#endif
+    uint32_t m[NL], out[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        acc = mad_carry_in(a[0], b[k], acc);
+#pragma unroll
+        for (int i = 1; i <= k; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::P[k - i];
+        m[k] = ((uint32_t)acc * F::PINV) & M29;
+        acc += (uint64_t)m[k] * F::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+        acc = mad_carry_in(a[k - (NL - 1)], b[NL - 1], acc);
+#pragma unroll
+        for (int i = k - (NL - 1) + 1; i < NL; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)m[i] * F::P[k - i];
+        acc += e[k - NL];
+        out[k - NL] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    out[NL - 1] = (uint32_t)acc + e[NL - 1];
+#pragma unroll
+    for (int i = 0; i < NL; i++) a[i] = out[i];
+}
+template <class F> BB_HD void sqr_addhi_raw(const uint32_t (&a)[NL], const uint32_t (&e)[NL], uint32_t (&out)[NL])
+{
+#if BBGPU_MONT_ASM
+    sqr_addhi_raw_gfx950<F>(a, e, out);
+    return;
+#endif
+    uint32_t t[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) t[i] = a[i];
+    mul_addhi_raw_inplace<F>(t, a, e); // the host form: the plain product (the device form saves the 36 symmetric multiply-adds)
+#pragma unroll
+    for (int i = 0; i < NL; i++) out[i] = t[i];
+}
+
 constexpr int mul_v(int v1, int v2)
 {
     return (v1 * v2) / 169 + 2;
@@ -413,6 +466,28 @@ BB_HD Fe<F, 1, mul2_v(V1, V2, V3, V4)> mul_add_ip(const Fe<F, L1, V1>& a, const 
 #pragma unroll
     for (int i = 0; i < NL; i++) r.d[i] = c.d[i];
     mul2_raw_inplace<F>(a.d, b.d, r.d, d.d);
+    return r;
+}
+
+// REDC(a b) + e with the result in a's registers and exact limbs (see mul_addhi_raw_inplace); e: any limb bound
+template <class F, int L1, int V1, int L2, int V2, int L3, int V3>
+BB_HD FeE<F, mul_v(V1, V2) + V3> mul_addhi_ip(const Fe<F, L1, V1>& a, const Fe<F, L2, V2>& b, const Fe<F, L3, V3>& e)
+{
+    static_assert(L1 * L2 <= 6, "limb bounds too large: weak() an operand");
+    static_assert(mul_v(V1, V2) + V3 <= MAXV, "value bound too large");
+    FeE<F, mul_v(V1, V2) + V3> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.d[i] = a.d[i];
+    mul_addhi_raw_inplace<F>(r.d, b.d, e.d);
+    return r;
+}
+// REDC(a^2) + e, exact limbs
+template <class F, int L1, int V1, int L3, int V3> BB_HD FeE<F, mul_v(V1, V1) + V3> sqr_addhi(const Fe<F, L1, V1>& a, const Fe<F, L3, V3>& e)
+{
+    static_assert(L1 * L1 <= 6, "limb bound too large for the squaring: weak() the operand");
+    static_assert(mul_v(V1, V1) + V3 <= MAXV, "value bound too large");
+    FeE<F, mul_v(V1, V1) + V3> r;
+    sqr_addhi_raw<F>(a.d, e.d, r.d);
     return r;
 }
 

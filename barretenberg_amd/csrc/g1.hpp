@@ -132,10 +132,17 @@ template <int V> BB_HD void madd(Xyzz& acc, const AffineV<V>& a)
 // a.x, a.y: the operand (y already negated where the digit is negative), consumed.
 template <int VX, int VY> BB_HD void madd_ip(Xyzz& acc, bool& acc_inf, const Fe<Fq, 1, VX>& ax, const Fe<Fq, 1, VY>& ay)
 {
+#ifdef BBGPU_MADD_NO_ADDHI // round 3's form, kept for A/B builds
     auto U2 = mul_ip(ax, acc.zz);
     auto S2 = mul_ip(ay, acc.zzz);
     auto P = weak(sub(U2, acc.x));
     auto R = weak(sub(S2, acc.y));
+#else
+    // round 4: the two differences come out of their products' own reductions -- P = REDC(x2 ZZ1 + (K p - X1) 2^261), nine more additions inside the
+    // carry chain instead of a subtraction (18 instructions) and a renormalisation (24) behind it -- with exact limbs
+    auto P = mul_addhi_ip(ax, acc.zz, neg(acc.x));
+    auto R = mul_addhi_ip(ay, acc.zzz, neg(acc.y));
+#endif
     auto PP = sqr(P);
     constexpr Limbs9 p2 = make_multiple<Fq>(2);
     const bool same_x = (PP.d[0] == 0 || PP.d[0] == Fq::P[0] || PP.d[0] == p2.d[0]) && is_zero_mulout(PP); // rare
@@ -159,7 +166,11 @@ template <int VX, int VY> BB_HD void madd_ip(Xyzz& acc, bool& acc_inf, const Fe<
         auto ZZ3 = mul_ip(acc.zz, PP);
         auto PPP = mul_ip(P, PP);
         auto Q = mul_ip(PP, acc.x);
+#ifdef BBGPU_MADD_NO_ADDHI
         auto X3 = carry_full(sub(sqr(R), add(PPP, dbl(Q))));
+#else
+        auto X3 = sqr_addhi(R, neg(add(PPP, dbl(Q)))); // R^2 - (PPP + 2 Q) with exact limbs, no carry_full
+#endif
         auto ZZZ3 = mul_ip(acc.zzz, PPP);
         auto Y3 = mul_add_ip(R, sub(Q, X3), neg(acc.y), PPP);
         acc.x = X3;

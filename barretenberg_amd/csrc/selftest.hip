@@ -96,6 +96,18 @@ template <class F> __global__ void selftest_field_kernel(const uint64_t* a_in, c
         o[1] = o[2] = o[3] = 0;
         break;
     }
+    case BBGPU_SELFTEST_MUL_ADDHI: {                                                      // a b - a: REDC(a b) + (K p - a), exact limbs out
+        // operands as the accumulation has them: one factor in Montgomery-261 form (a table point), the other and the addend in memory form
+        const auto r = mul_addhi_ip(A, m256_to_m261<F>(B), neg(A));
+        st_canonical(o, r);
+        break;
+    }
+    case BBGPU_SELFTEST_SQR_ADDHI: {                                                      // a^2 - (b + 2a), the addend with limbs up to 5 U
+        const auto X = m256_to_m261<F>(A);                          // a 2^261
+        const auto E = neg(add(m256_to_m261<F>(B), dbl(X)));        // K p - (b + 2a) 2^261
+        st_canonical(o, m261_to_m256<F>(sqr_addhi(X, E)));
+        break;
+    }
     default: o[0] = o[1] = o[2] = o[3] = ~0ull;
     }
 }

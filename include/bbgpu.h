@@ -339,7 +339,9 @@ enum {
     BBGPU_SELFTEST_LAZY_VALUE = 9, /* 28 a                        value bound at its maximum, 168 p < 2^261, through the multiplier */
     BBGPU_SELFTEST_REDUCE = 10,    /* 28 a                        the same through reduce_value() */
     BBGPU_SELFTEST_SQR_LAZY = 11,  /* (2a - b)^2 */
-    BBGPU_SELFTEST_ZERO_TESTS = 12 /* limb 0: bit 0 = (a - b == 0), bit 1 = ((a - b) a == 0) */
+    BBGPU_SELFTEST_ZERO_TESTS = 12,/* limb 0: bit 0 = (a - b == 0), bit 1 = ((a - b) a == 0) */
+    BBGPU_SELFTEST_MUL_ADDHI = 13, /* a b - a                     the product with a third operand added inside its reduction (in place; the mixed addition's P and R) */
+    BBGPU_SELFTEST_SQR_ADDHI = 14  /* a^2 - (b + 2a)              the same for the squaring, addend with unnormalised limbs (the mixed addition's X3) */
 };
 enum {
     BBGPU_SELFTEST_G1_MADD = 0,      /* p + (q.x, q.y)                                             g1::mixed_add, group.hpp:219-322 */

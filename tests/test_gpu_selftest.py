@@ -35,6 +35,7 @@ def _expected(op, a, b, p):
         "mul_add": (mm(a, b) + mm(a + b, a - b)) % p, "mul_sub": (mm(a, b) - mm(2 * a, b)) % p,
         "lazy_limbs": mm(2 * a, 3 * b), "lazy_weak": mm(4 * a, b - a), "lazy_value": 28 * a % p, "reduce": 28 * a % p,
         "sqr_lazy": mm(2 * a - b, 2 * a - b),
+        "mul_addhi": (mm(a, b) - a) % p, "sqr_addhi": (mm(a, a) - b - 2 * a) % p,
     }[op]
 
 
@@ -84,7 +85,7 @@ def test_device_field_lazy_bounds(gpu, oracle, field):
     pairs = [(x, y) for x in special for y in special[:9]] + list(zip(vals, reversed(vals))) + [(v, v) for v in vals[:40]]
     a = np.stack([from_int(x) for x, _ in pairs])
     b = np.stack([from_int(y) for _, y in pairs])
-    for op in ("mul", "sqr", "add", "sub", "neg", "mul_add", "mul_sub", "lazy_limbs", "lazy_weak", "lazy_value", "reduce", "sqr_lazy"):
+    for op in ("mul", "sqr", "add", "sub", "neg", "mul_add", "mul_sub", "lazy_limbs", "lazy_weak", "lazy_value", "reduce", "sqr_lazy", "mul_addhi", "sqr_addhi"):
         got = _ints(gpu.selftest_field(field, op, a, b))
         for (x, y), g in zip(pairs, got):
             assert g == _expected(op, x, y, p), (field, op, hex(x), hex(y))

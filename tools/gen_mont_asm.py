@@ -45,11 +45,16 @@ def low_column(ins, k, prods, q="r"):
     ins.append(f"v_lshrrev_b64 {ACC}, 29, {ACC}")
 
 
-def high_column(ins, k, prods, q="r", o="r"):
+def high_column(ins, k, prods, q="r", o="r", e=None):
     for (x, y) in prods:
         ins.append(mad(x, y, False))
     for i in range(k - (NL - 1), NL):
         ins.append(mad(f"%[{q}{i}]", f"%[p{k - i}]", False))
+    # "addhi" forms (e = name of a third operand): out = REDC(a b) + e, i.e. e * 2^261 is added to the double-width product -- limb j of e goes
+    # into column j + 9 as one more multiply-add (by the constant 1, an SGPR: the cheaper form of the instruction).  The sum then comes out of
+    # the product's own carry chain with exact limbs: a difference U - X needs no separate subtraction and renormalisation (fe.hpp mul_addhi).
+    if e is not None:
+        ins.append(mad(f"%[{e}{k - NL}]", "%[one]", False))
     # r[k-9] is dead as a Montgomery quotient digit from column k-1 on (m[i] is last used in column i+8)
     if k < 2 * NL - 2:
         ins.append(f"v_and_b32 %[{o}{k - NL}], {MASK}, {ACC_LO}")
@@ -58,16 +63,18 @@ def high_column(ins, k, prods, q="r", o="r"):
         # last column: limb 7 and the (unmasked) top limb; r8 = m[8] (or the operand's limb 8) was an operand of this column's mads
         ins.append(f"v_and_b32 %[{o}7], {MASK}, {ACC_LO}")
         ins.append(f"v_alignbit_b32 %[{o}8], {ACC_HI}, {ACC_LO}, 29")
+        if e is not None:
+            ins.append(f"v_add_u32 %[{o}8], %[{o}8], %[{e}8]")
 
 
-def gen_mul(q="r", o="r"):
+def gen_mul(q="r", o="r", e=None):
     ins = []
     for k in range(2 * NL - 1):
         prods = [(f"%[a{i}]", f"%[b{k - i}]") for i in range(NL) if 0 <= k - i < NL]
         if k < NL:
             low_column(ins, k, prods, q)
         else:
-            high_column(ins, k, prods, q, o)
+            high_column(ins, k, prods, q, o, e)
     return ins
 
 
@@ -86,7 +93,7 @@ def gen_mul2(q="r", o="r"):
     return ins
 
 
-def gen_sqr():
+def gen_sqr(e=None):
     ins = [f"v_lshlrev_b32 %[t{i}], 1, %[a{i}]" for i in range(NL - 1)]
     for k in range(2 * NL - 1):
         prods = []
@@ -96,7 +103,10 @@ def gen_sqr():
             j = k - i
             if i < j < NL:
                 prods.append((f"%[t{i}]", f"%[a{j}]"))
-        (low_column if k < NL else high_column)(ins, k, prods)
+        if k < NL:
+            low_column(ins, k, prods)
+        else:
+            high_column(ins, k, prods, e=e)
     return ins
 
 
@@ -107,7 +117,7 @@ def count(ins):
     return c
 
 
-def emit_fn(name, sig, ins, outs, ins_v, temps):
+def emit_fn(name, sig, ins, outs, ins_v, temps, one=False):
     lines = []
     lines.append(f"// {name}: " + ", ".join(f"{v} {k}" for k, v in sorted(count(ins).items())) + f" = {len(ins)} instructions")
     lines.append(f"template <class F> __device__ __forceinline__ void {name}({sig})")
@@ -119,7 +129,7 @@ def emit_fn(name, sig, ins, outs, ins_v, temps):
         lines.append(f'        "{s}\\n\\t"')
     lines.append("        : " + ", ".join(outs))
     lines.append("        : " + ", ".join(ins_v) + ",")
-    lines.append("          " + ", ".join(f'[p{i}] "s"(F::P[{i}])' for i in range(NL)) + ', [pinv] "s"(F::PINV)')
+    lines.append("          " + ", ".join(f'[p{i}] "s"(F::P[{i}])' for i in range(NL)) + ', [pinv] "s"(F::PINV)' + (', [one] "s"(1u)' if one else ""))
     lines.append(f"        : {CLOBBERS});")
     lines.append("}")
     return "\n".join(lines)
@@ -156,6 +166,12 @@ def main():
     print()
     print(emit_fn("mul2_raw_inplace_gfx950", "const uint32_t (&a)[9], const uint32_t (&b)[9], uint32_t (&c)[9], const uint32_t (&d)[9]",
                   gen_mul2("m", "c"), c_io + m_out, a_in + b_in + d_in, m_tmp))
+    print()
+    # "addhi" forms: REDC(a b) + e and REDC(a^2) + e with e's limbs added inside the product's carry chain (exact limbs out)
+    e_in = [f'[e{i}] "v"(e[{i}])' for i in range(NL)]
+    print(emit_fn("mul_addhi_raw_inplace_gfx950", "uint32_t (&a)[9], const uint32_t (&b)[9], const uint32_t (&e)[9]", gen_mul("m", "a", "e"), a_io + m_out, b_in + e_in, m_tmp, one=True))
+    print()
+    print(emit_fn("sqr_addhi_raw_gfx950", "const uint32_t (&a)[9], const uint32_t (&e)[9], uint32_t (&out)[9]", gen_sqr("e"), outs + t_out, a_in + e_in, [f"t{i}" for i in range(NL - 1)], one=True))
     print("} // namespace bbgpu")
 
 
