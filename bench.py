@@ -801,12 +801,11 @@ def main():
                     rocprof_frac = alg_bytes / (rocprof_spacing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 break
         share_adds = (W * (pt1 - pt0)) if by_points else (W * n // world) if by_buckets else (rows[1] - rows[0]) if by_rows else n * (we - wb)  # mixed additions of this rank's accumulation (expected, for bucket shares)
-        # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition (round-3 loop: 2,142 instructions in the hot
-        # path + ~85 in the bucket-start block that ~1 trip in 4 runs) = 738 v_mad_u64_u32 with two VGPR factors + 729 with an SGPR factor
-        # + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 194 v_and_b32 + ~275 other VALU (DESIGN_HISTORY.md 5), priced at the measured chip-wide issue rates of
-        # tools/ubench/ubench_inst (445 / 489 / 565 / 537 / 916 / ~850 G wave-instructions/s): 4.04 ns of chip time per wave-addition = the
-        # floor this instruction stream allows (round 2: 209 ands, ~430 others, 4.24 ns)
-        ns_per_wave_add = 738 / 445.0 + 729 / 489.0 + 144 / 565.0 + 81 / 537.0 + 194 / 916.0 + 275 / 850.0
+        # the bound that does apply to the accumulation: instruction issue.  One mixed XYZZ addition (round-4 loop, ISA histogram tools/isa_hist.py: 2,048 VALU instructions
+        # in the hot path + ~85 in the bucket-start block that ~1 trip in 4 runs) = 738 v_mad_u64_u32 with two VGPR factors + 753 with an SGPR factor (729 of the reductions,
+        # 24 that add P / R / X3's addends inside them) + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 + 170 v_and_b32 + ~162 other VALU, priced at the measured chip-wide issue rates of
+        # tools/ubench/ubench_inst (445 / 489 / 565 / 537 / 916 / ~850 G wave-instructions/s) = the floor this instruction stream allows (round 3: 2,110 instructions, 4.04 ns)
+        ns_per_wave_add = 738 / 445.0 + 753 / 489.0 + 144 / 565.0 + 81 / 537.0 + 170 / 916.0 + 162 / 850.0
         issue_floor_ms = share_adds / 64 * ns_per_wave_add * 1e-6
         line = {
             "metric": "BN254 G1 MSM points/sec at n=2^%d (Fr NTT elems/sec in 'ntt')" % args.log2n,
