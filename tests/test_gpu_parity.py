@@ -348,8 +348,9 @@ def test_msm_fuzz_sizes_and_distributions(gpu, oracle, msm_small):
 
 
 def test_msm_additivity_large(gpu, oracle):
-    """sizes beyond the golden fixtures (non-power-of-two, and 2^21 which exceeds the window-table limit):
-    MSM(n) == MSM(first half) + MSM(second half), through independent code paths (different n => different chunking)"""
+    """sizes beyond the round-1 fixtures (non-power-of-two, and 2^21 = two window-table segments, or per-window bucket sets in the no-tables pass):
+    MSM(n) == MSM(first half) + MSM(second half), through independent code paths (different n => different chunking; the cut is not the segment
+    boundary).  Reference points for 2^21 and 2^20 + 8: test_msm_beyond_one_table_segment."""
     import torch
     x = oracle.random_scalars(SRS_SEED + 1, 1)[0]
     for n in (3 << 18, 1 << 21):
