@@ -322,3 +322,18 @@ def test_transform_tables_stay_under_their_byte_budget(gpu, oracle, golden):
         del os.environ["BBGPU_NTT_TABLE_BYTES"]
     m = gpu.memory_stats()
     assert m["msm_workspace_bytes"] >= 0 and m["staging_bytes"] > 0 and m["pinned_host_bytes"] > 0
+
+
+def test_reference_calling_pattern_openmp_pippenger(tmp_path):
+    """scalar_multiplication.cpp:703-738 as the reference does it, through the shim's mangled symbols: OpenMP threads call pippenger() on sub-slices of one
+    resident point table at the same time (and fft / ifft on buffers of their own); their partial sums add up to the one-call result.  8 threads at
+    2^16 points, 5 at 100,003 (ragged ranges).  BBGPU_SHIM_STRICT=1: no host answer may stand in for a kernel."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "barretenberg_amd")
+    exe = str(tmp_path / "test_shim_omp")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-fopenmp", "-Wno-invalid-offsetof", "-o", exe, os.path.join(root, "tests", "cpp", "test_shim_omp.cpp"), "-L" + pkg, "-lbbshim", "-lbbgpu",
+                    "-Wl,-rpath," + pkg], check=True)
+    for n, threads in ((1 << 16, 8), (100003, 5)):
+        r = subprocess.run([exe, str(n), str(threads)], capture_output=True, text=True, timeout=300, env=dict(os.environ, BBGPU_SHIM_STRICT="1"))
+        assert r.returncode == 0 and "ALL OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
