@@ -76,6 +76,24 @@ def test_ntt_golden_digests(gpu, oracle, golden, log2n):
         assert sha(got) == case["sha256"], (log2n, case["kind"])
 
 
+@pytest.mark.parametrize("log2n", [23, 24])
+def test_ntt_golden_digests_extended_domain_sizes(gpu, oracle, golden, log2n):
+    """outputs of the reference itself at 2^23 and 2^24 (tests/golden/big_r4.json, tools/gen_golden_r4b.py): the 4n coset domain of a 2^21 /
+    2^22-gate circuit; all seven kinds, sha256 + sampled elements"""
+    g = golden("big_r4.json")
+    c = limbs(g["constant"])
+    n = 1 << log2n
+    co = noncanonical(oracle.random_scalars(NTT_SEED, n), FR_MODULUS)
+    cases = [x for x in g["ntt"] if x["n"] == n]
+    assert len(cases) == 7
+    for case in cases:
+        got = gpu.ntt(co.copy(), case["kind"], c)
+        for i, v in case["samples"].items():
+            assert np.array_equal(got[int(i)], limbs(v)), (log2n, case["kind"], i)
+        assert sha(got) == case["sha256"], (log2n, case["kind"])
+        del got
+
+
 def test_ntt_fft_matches_direct_evaluation(gpu, oracle):
     """test_polynomial_arithmetic.cpp:31-56"""
     n = 16
@@ -643,6 +661,27 @@ def test_msm_beyond_one_table_segment(gpu, oracle, golden):
         from barretenberg_amd import BbGpuError
         with pytest.raises(BbGpuError, match="ONE table segment"):
             gpu.msm_device_rows_async(h, d_sc.data_ptr(), N, 0, N)
+    gpu.srs_release(h)
+
+
+def test_msm_four_table_segments(gpu, oracle, golden):
+    """n = 2^22 and n = 3 * 2^20 + 11 on a 2^22-point SRS (four window-table segments; the ragged size leaves the last one partly used): points the
+    REFERENCE computed (tests/golden/big_r4.json, tools/gen_golden_r4b.py), through the device entry, the host-pointer entry and a two-job batch"""
+    import torch
+    g = golden("big_r4.json")
+    N = 1 << 22
+    h, table = gpu.srs_generate(limbs(g["srs_secret_mont"]), N, True)
+    assert sha(table[0::2]) == g["srs_digest_%d" % N]
+    scalars = oracle.random_scalars(SCALAR_SEED, N)
+    d_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
+    for case in g["msm"]:
+        n = case["n"]
+        _check(gpu.msm_device(h, d_sc.data_ptr(), n), case)
+        _check(gpu.pippenger(aligned_copy(scalars[:n]), table, n), case)
+    if gpu.srs_has_window_tables(h):  # the batched entry needs them
+        got = gpu.msm_batch_wait(gpu.msm_device_batch_async(h, [d_sc.data_ptr(), d_sc.data_ptr()], N))
+        _check(got[0], g["msm"][-1])
+        _check(got[1], g["msm"][-1])
     gpu.srs_release(h)
 
 
