@@ -51,7 +51,7 @@ C_ABI_SYMBOLS = [
     "bbgpu_plonk_prover_create", "bbgpu_plonk_prover_set_witness", "bbgpu_plonk_construct_proof", "bbgpu_plonk_preprocess", "bbgpu_plonk_last_challenges",
     "bbgpu_plonk_last_timing", "bbgpu_plonk_prover_destroy", "bbgpu_plonk_challenges_from_proof",
     "bbgpu_host_msm_g1", "bbgpu_host_ntt", "bbgpu_host_fr_evaluate", "bbgpu_host_kate_opening", "bbgpu_host_lagrange_l1_fft",
-    "bbgpu_host_divide_by_pseudo_vanishing", "bbgpu_memory_stats",
+    "bbgpu_host_divide_by_pseudo_vanishing", "bbgpu_memory_stats", "bbgpu_fault_inject", "bbgpu_fault_stats", "bbgpu_srs_set_validate",
 ]
 
 
@@ -59,6 +59,12 @@ class MemoryInfo(C.Structure):
     """bbgpu_memory_info (include/bbgpu.h)"""
     _fields_ = [(k, C.c_uint64) for k in ("srs_points_bytes", "srs_table_bytes", "srs_auto_bytes", "srs_cache_cap_bytes", "ntt_table_bytes", "ntt_table_cap_bytes",
                                           "ntt_table_sets", "msm_workspace_bytes", "staging_bytes", "pinned_host_bytes")]
+
+
+class FaultInfo(C.Structure):
+    """bbgpu_fault_info (include/bbgpu.h)"""
+    _fields_ = [(k, C.c_uint64) for k in ("alloc_calls", "h2d_calls", "d2h_calls", "launch_checks", "armed", "fired", "absorbed", "live_allocations",
+                                          "live_bytes", "slots_pending")]
 
 
 class BbGpuError(RuntimeError):
@@ -106,6 +112,8 @@ class BbGpu:
         if hasattr(L, "bbgpu_srs_generate_range"):  # absent from older A/B builds loaded through BBGPU_LIB
             L.bbgpu_srs_generate_range.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p]
         L.bbgpu_msm_g1.argtypes = [u64p, u64p, C.c_size_t, u64p]
+        if hasattr(L, "bbgpu_fault_inject"):  # absent from older A/B builds loaded through BBGPU_LIB
+            L.bbgpu_fault_inject.argtypes = [C.c_char_p]
         L.bbgpu_msm_g1_plain.argtypes = [u64p, u64p, C.c_size_t, u64p]
         L.bbgpu_msm_g1_batch.argtypes = [C.POINTER(MsmJob), C.c_size_t]
         L.bbgpu_msm_num_windows.argtypes = [C.c_size_t]
@@ -245,6 +253,20 @@ class BbGpu:
         info = MemoryInfo()
         self._chk(self.lib.bbgpu_memory_stats(C.byref(info)))
         return {k: int(getattr(info, k)) for k, _ in MemoryInfo._fields_}
+
+    def fault_inject(self, spec):
+        """testing: "alloc:k" | "h2d:k" | "d2h:k" | "launch:k" makes the k-th such call from now on fail once; None disarms (bbgpu_fault_inject)"""
+        self._chk(self.lib.bbgpu_fault_inject(spec.encode() if spec else None))
+
+    def fault_stats(self):
+        """funnel counters since the last spec, live device allocations, MSM slots in flight, as a dict (bbgpu_fault_stats)"""
+        info = FaultInfo()
+        self._chk(self.lib.bbgpu_fault_stats(C.byref(info)))
+        return {k: int(getattr(info, k)) for k, _ in FaultInfo._fields_}
+
+    def srs_set_validate(self, handle, full):
+        """exact mode of the address-keyed table cache: host-pointer MSMs re-hash every row they use (handle -1: default for tables registered from now on)"""
+        self._chk(self.lib.bbgpu_srs_set_validate(int(handle), 1 if full else 0))
 
     def srs_release(self, handle):
         self._chk(self.lib.bbgpu_srs_release(handle))

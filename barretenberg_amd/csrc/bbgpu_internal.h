@@ -12,6 +12,27 @@ namespace bbgpu {
 
 void set_error(const char* fmt, ...);
 
+// capi.hip: EVERY device allocation, host<->device copy of a caller's buffer and launch check of the library goes through these four, so that
+// (i) a test can make the k-th one fail on a machine that HAS a GPU (BBGPU_FAIL_AT / bbgpu_fault_inject: "alloc:k", "h2d:k", "d2h:k", "launch:k" -- the
+// error contract of the drop-in boundary, SURVEY 8b "Errors"; no kernel reads any of this) and (ii) the live device allocations are counted
+// (bbgpu_fault_stats: a leak on an error path shows as allocations that outlive bbgpu_shutdown()).
+hipError_t dev_malloc(void** p, size_t bytes);
+hipError_t dev_free(void* p);
+hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st);
+hipError_t d2h_async(void* dst, const void* src, size_t bytes, hipStream_t st);
+hipError_t launch_check(); // hipGetLastError() after a launch (or a chain of launches)
+// a device buffer that is freed on every way out of a function unless it was handed on (release())
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)dev_free(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+    template <class T> T* release() { T* r = static_cast<T*>(p); p = nullptr; return r; }
+};
+void fault_absorbed();     // a failure the library rode out by itself (an SRS kept without its window tables): counted, so a test can tell it from a lost injection
+
 // ntt.hip
 int ntt_device(uint64_t* d_coeffs, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256, hipStream_t st);
 int ntt_device_batch(uint64_t* d_coeffs, size_t stride_elems, int batch, uint64_t* d_scratch, int log2n, int kind, const uint64_t* constant_m256,
@@ -84,7 +105,7 @@ int srs_generate(const uint64_t* x_mont256, size_t first, size_t n, uint32_t** d
 
 // capi.hip: the caller's host buffers cross the link through the library's OWN pinned buffers (see host_to_device)
 int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
-int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st);
+int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st, bool* touched = nullptr); // *touched: h_dst may have been written (even on failure)
 void host_stage_release();
 int bind_calling_thread(); // initialises the library if need be and makes the bound device the calling thread's current one (HIP's current device is per thread)
 

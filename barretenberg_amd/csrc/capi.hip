@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <atomic>
+#include <unordered_map>
 #include <vector>
 
 #include "bbgpu_internal.h"
@@ -30,6 +32,147 @@ void set_error(const char* fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- the funnels of bbgpu_internal.h: allocation accounting + fault injection ---------------------------------------------------------------
+// BBGPU_FAIL_AT (read once, when the first funnel is reached) or bbgpu_fault_inject(): "<kind>:<k>" with kind in alloc | h2d | d2h | launch makes the
+// k-th call (k = 0: the next one) of that kind fail ONCE with the error a real failure of that kind returns, without touching the device; the
+// call after it works again.  Counters restart whenever a spec is set.  Host-side only: no kernel reads any of it.
+namespace {
+enum FaultKind { F_ALLOC = 0, F_H2D = 1, F_D2H = 2, F_LAUNCH = 3, F_KINDS = 4 };
+struct FaultState {
+    std::mutex mu;
+    std::atomic<int> armed_kind{ -1 };   // -1: nothing armed (the one load every funnel call pays)
+    uint64_t fail_at = 0;
+    std::atomic<uint64_t> calls[F_KINDS] = {};
+    std::atomic<uint64_t> fired{ 0 }, absorbed{ 0 };
+    std::unordered_map<void*, size_t> live; // device allocations of the library that are live now
+    uint64_t live_bytes = 0;
+    bool env_read = false;
+};
+FaultState& fault()
+{
+    static FaultState* f = new FaultState(); // never destroyed: funnels run during static destruction of other objects too
+    return *f;
+}
+int fault_parse(const char* spec, int* kind, uint64_t* at)
+{
+    static const char* names[F_KINDS] = { "alloc", "h2d", "d2h", "launch" };
+    if (!spec || !*spec) { *kind = -1; return 0; }
+    for (int k = 0; k < F_KINDS; k++) {
+        const size_t len = strlen(names[k]);
+        if (!strncmp(spec, names[k], len) && spec[len] == ':') {
+            char* end = nullptr;
+            *at = strtoull(spec + len + 1, &end, 0);
+            if (end == spec + len + 1 || *end) return -1;
+            *kind = k;
+            return 0;
+        }
+    }
+    return -1;
+}
+int fault_set(const char* spec)
+{
+    FaultState& F = fault();
+    int kind = -1;
+    uint64_t at = 0;
+    if (fault_parse(spec, &kind, &at)) return -1;
+    std::lock_guard<std::mutex> lk(F.mu);
+    F.env_read = true; // an explicit spec overrides the environment
+    for (auto& c : F.calls) c.store(0);
+    F.fired.store(0);
+    F.absorbed.store(0);
+    F.fail_at = at;
+    F.armed_kind.store(kind);
+    return 0;
+}
+// true: this call is the one to fail
+bool fault_hit(FaultKind kind)
+{
+    FaultState& F = fault();
+    if (!F.env_read) {
+        std::lock_guard<std::mutex> lk(F.mu);
+        if (!F.env_read) {
+            F.env_read = true;
+            int k = -1;
+            uint64_t at = 0;
+            const char* e = getenv("BBGPU_FAIL_AT"); // testing: "alloc:k" / "h2d:k" / "d2h:k" / "launch:k" makes the k-th such call of the process fail once (include/bbgpu.h, bbgpu_fault_inject)
+            if (e && fault_parse(e, &k, &at) == 0 && k >= 0) {
+                F.fail_at = at;
+                F.armed_kind.store(k);
+            } else if (e && *e) {
+                fprintf(stderr, "bbgpu: BBGPU_FAIL_AT=%s not understood (alloc:k | h2d:k | d2h:k | launch:k)\n", e);
+            }
+        }
+    }
+    const uint64_t n = F.calls[kind].fetch_add(1);
+    if (F.armed_kind.load(std::memory_order_relaxed) != (int)kind) return false;
+    std::lock_guard<std::mutex> lk(F.mu);
+    if (F.armed_kind.load() != (int)kind || n != F.fail_at) return false;
+    F.armed_kind.store(-1); // one shot
+    F.fired.fetch_add(1);
+    return true;
+}
+} // namespace
+
+hipError_t dev_malloc(void** p, size_t bytes)
+{
+    if (fault_hit(F_ALLOC)) {
+        *p = nullptr;
+        set_error("hipMalloc(%zu bytes) -> %s [injected by BBGPU_FAIL_AT]", bytes, hipGetErrorString(hipErrorOutOfMemory));
+        return hipErrorOutOfMemory;
+    }
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && *p) {
+        FaultState& F = fault();
+        std::lock_guard<std::mutex> lk(F.mu);
+        F.live[*p] = bytes;
+        F.live_bytes += bytes;
+    }
+    return e;
+}
+hipError_t dev_free(void* p)
+{
+    if (!p) return hipSuccess;
+    {
+        FaultState& F = fault();
+        std::lock_guard<std::mutex> lk(F.mu);
+        auto it = F.live.find(p);
+        if (it != F.live.end()) {
+            F.live_bytes -= it->second;
+            F.live.erase(it);
+        }
+    }
+    return hipFree(p);
+}
+hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (fault_hit(F_H2D)) {
+        set_error("hipMemcpyAsync(host to device, %zu bytes) -> %s [injected by BBGPU_FAIL_AT]", bytes, hipGetErrorString(hipErrorInvalidValue));
+        return hipErrorInvalidValue;
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+}
+hipError_t d2h_async(void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (fault_hit(F_D2H)) {
+        set_error("hipMemcpyAsync(device to host, %zu bytes) -> %s [injected by BBGPU_FAIL_AT]", bytes, hipGetErrorString(hipErrorInvalidValue));
+        return hipErrorInvalidValue;
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+}
+hipError_t launch_check()
+{
+    const hipError_t e = hipGetLastError(); // a real failure is reported (and cleared) first
+    if (e != hipSuccess) return e;
+    if (fault_hit(F_LAUNCH)) {
+        set_error("kernel launch -> %s [injected by BBGPU_FAIL_AT]", hipGetErrorString(hipErrorLaunchFailure));
+        return hipErrorLaunchFailure;
+    }
+    return hipSuccess;
+}
+void fault_absorbed() { fault().absorbed.fetch_add(1); }
+
+static host::CopyPool g_copy_pool; // CPU copies into / out of the pinned staging buffers (host_copy_pool.hpp); also hashes point tables (exact cache mode)
 
 namespace {
 
@@ -58,16 +201,20 @@ struct SrsEntry {
     size_t bytes = 0; // device bytes held (points + window tables)
     bool handle_exposed = false; // the index was returned to a caller as a handle: the slot is never reused for another table
     uint64_t check_phase = 0;    // rotates the rows a content check samples (contents_match)
+    bool stale_for_host = false; // exact mode found the caller's memory changed under an EXPLICITLY registered table: host-pointer calls no longer use it (the handle stays valid)
+    bool validate_full = false;  // EXACT mode (bbgpu_srs_set_validate / BBGPU_SRS_VALIDATE=full): every host-pointer MSM re-hashes the whole range it uses
 };
 
+// eight independent multiplications (odd multipliers: a change of one limb always changes the sum) instead of a dependent chain: the full content
+// check of BBGPU_SRS_VALIDATE=full hashes every row of the range on every call and must run at memory speed
 inline uint64_t hash_row(const uint64_t* row8)
 {
-    uint64_t h = 0x9e3779b97f4a7c15ULL;
-    for (int i = 0; i < 8; i++) {
-        h = (h ^ row8[i]) * 0xbf58476d1ce4e5b9ULL;
-        h ^= h >> 29;
-    }
-    return h;
+    static const uint64_t M[8] = { 0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL, 0x94d049bb133111ebULL, 0xd6e8feb86659fd93ULL,
+                                   0xca5a826395121157ULL, 0xff51afd7ed558ccdULL, 0xc4ceb9fe1a85ec53ULL, 0x2545f4914f6cdd1dULL };
+    uint64_t h = 0;
+    for (int i = 0; i < 8; i++) h += (row8[i] ^ M[(i + 3) & 7]) * M[i];
+    h ^= h >> 31;
+    return h * 0x9e3779b97f4a7c15ULL;
 }
 
 struct Context {
@@ -88,6 +235,7 @@ struct Context {
     bool precompute = true; // build window tables for registered SRS (bbgpu_set_precompute)
     uint64_t use_clock = 0;  // LRU clock of the SRS cache
     size_t srs_cache_cap = (size_t)16 << 30; // device bytes the auto-registered tables may hold together (BBGPU_SRS_CACHE_BYTES)
+    bool srs_validate_full = false;          // default of SrsEntry::validate_full for tables registered from now on
     // SURVEY 8b "small sizes": host-pointer MSMs of at most host_msm_max points against tables that are not resident, and host-buffer
     // transforms of at most host_ntt_max elements, are answered on the host (host_small.hpp); bbgpu_set_host_thresholds / BBGPU_HOST_MSM_MAX /
     // BBGPU_HOST_NTT_MAX.  Defaults from tools/small_sizes.py on MI355X + EPYC 9575F: MSM n = 4 / 20 / 32 / 64 host 0.16 / 0.31 / 0.41 /
@@ -174,6 +322,7 @@ int ensure_init()
     CHK(hipEventCreateWithFlags(&g_ctx.shared_done, hipEventDisableTiming));
     g_ctx.shared_used = false;
     if (const char* e = getenv("BBGPU_SRS_CACHE_BYTES")) g_ctx.srs_cache_cap = (size_t)strtoull(e, nullptr, 0);
+    if (const char* e = getenv("BBGPU_SRS_VALIDATE")) g_ctx.srs_validate_full = !strcmp(e, "full"); // full: host-pointer MSMs re-hash every row they use on every call (exact, ~+0.1 ms per 2^16 points hidden behind the kernels); default: 16 sampled rows
     g_ctx.ready = true;
     return BBGPU_OK;
 }
@@ -197,10 +346,10 @@ int shared_end(hipStream_t st)
 int grow(uint64_t** buf, size_t* cap, size_t bytes)
 {
     if (bytes <= *cap) return BBGPU_OK;
-    if (*buf) (void)hipFree(*buf);
+    if (*buf) (void)dev_free(*buf);
     *buf = nullptr;
     *cap = 0;
-    CHK(hipMalloc((void**)buf, bytes));
+    CHK(dev_malloc((void**)buf, bytes));
     *cap = bytes;
     return BBGPU_OK;
 }
@@ -217,7 +366,6 @@ int grow(uint64_t** buf, size_t* cap, size_t bytes)
 // library's own: CPU memcpy (30-50 GB/s on the boxes' EPYC 9575F), DMA from / to pinned memory, the copy of chunk k+1 under the DMA of
 // chunk k.  Larger buffers keep the direct path: there a copy is 0.6 ms per 32 MiB against ~1 ms through one staging thread, and the
 // stall is small against the work (profiles/r03_pcie.txt).
-static host::CopyPool g_copy_pool; // CPU copies into / out of the pinned staging buffers (host_copy_pool.hpp)
 
 int bind_calling_thread()
 {
@@ -242,7 +390,7 @@ int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
     read_host_env();
     if (bytes == 0) return BBGPU_OK;
     if (bytes > g_ctx.host_stage_max) {
-        CHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+        CHK(h2d_async(d_dst, h_src, bytes, st));
         return BBGPU_OK;
     }
     if (int rc = host_stage_ensure()) return rc;
@@ -252,18 +400,22 @@ int host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st)
         const int k = (int)(g_ctx.h_stage_next++ % Context::HOST_RING);
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k])); // the DMA that last read this buffer has finished (no-op before its first use)
         g_copy_pool.copy(g_ctx.h_stage[k], (const char*)h_src + off, len);
-        CHK(hipMemcpyAsync((char*)d_dst + off, g_ctx.h_stage[k], len, hipMemcpyHostToDevice, st));
+        CHK(h2d_async((char*)d_dst + off, g_ctx.h_stage[k], len, st));
         CHK(hipEventRecord(g_ctx.h_stage_free[k], st));
     }
     return BBGPU_OK;
 }
-// device -> caller's buffer, complete on return (everything enqueued on `st` before it has run as well)
-int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st)
+// device -> caller's buffer, complete on return (everything enqueued on `st` before it has run as well).
+// *touched (optional): set when the call may have written ANY byte of h_dst -- on a failure that tells an in-place caller whether its input is still
+// whole (nothing touched: an ordinary error the shim answers on the host) or gone (BBGPU_ERR_LOST).
+int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_t st, bool* touched)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     read_host_env();
+    if (touched) *touched = false;
     if (bytes > g_ctx.host_stage_max) {
-        CHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        CHK(d2h_async(h_dst, d_src, bytes, st));
+        if (touched) *touched = true; // the DMA engine owns the destination from here on
         CHK(hipStreamSynchronize(st));
         return BBGPU_OK;
     }
@@ -277,7 +429,7 @@ int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_
         const int k = (int)(g_ctx.h_stage_next++ % Context::HOST_RING);
         kbuf[c % Context::HOST_RING] = k;
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k]));
-        CHK(hipMemcpyAsync(g_ctx.h_stage[k], (const char*)d_src + c * CH, std::min(CH, bytes - c * CH), hipMemcpyDeviceToHost, st));
+        CHK(d2h_async(g_ctx.h_stage[k], (const char*)d_src + c * CH, std::min(CH, bytes - c * CH), st));
         CHK(hipEventRecord(g_ctx.h_stage_free[k], st));
         return BBGPU_OK;
     };
@@ -295,6 +447,7 @@ int device_to_host_sync(void* h_dst, const void* d_src, size_t bytes, hipStream_
         }
         const int k = kbuf[c % Context::HOST_RING];
         CHK(hipEventSynchronize(g_ctx.h_stage_free[k]));
+        if (touched) *touched = true;
         g_copy_pool.copy((char*)h_dst + c * CH, g_ctx.h_stage[k], std::min(CH, bytes - c * CH));
     }
     return BBGPU_OK;
@@ -326,9 +479,9 @@ void free_entry(SrsEntry& e)
     if (trace_srs()) fprintf(stderr, "bbgpu srs: evict %p n=%zu auto=%d\n", (const void*)e.host_ptr, e.n, (int)e.auto_registered);
     // an asynchronous MSM may still be reading the table: drain the device first (rare path)
     (void)hipDeviceSynchronize();
-    if (e.d_srs) (void)hipFree(e.d_srs);
+    if (e.d_srs) (void)dev_free(e.d_srs);
     for (auto& sg : e.segs)
-        if (sg.d_tab_alloc) (void)hipFree(sg.d_tab_alloc);
+        if (sg.d_tab_alloc) (void)dev_free(sg.d_tab_alloc);
     e.segs.clear();
     e.d_srs = nullptr;
     e.live = false;
@@ -353,10 +506,15 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
     e.d_srs = d_srs;
     e.live = true;
     e.auto_registered = auto_registered;
+    e.validate_full = g_ctx.srs_validate_full;
     e.last_use = ++g_ctx.use_clock;
     if (host_ptr) {
         e.row_hash.resize(n);
-        for (size_t i = 0; i < n; i++) e.row_hash[i] = hash_row(host_ptr + i * 16);
+        struct Job { const uint64_t* p; uint64_t* h; } job{ host_ptr, e.row_hash.data() };
+        g_copy_pool.for_range(n, (size_t)1 << 14, [](void* c, size_t lo, size_t hi) {
+            const Job* j = static_cast<const Job*>(c);
+            for (size_t i = lo; i < hi; i++) j->h[i] = hash_row(j->p + i * 16);
+        }, &job);
     }
     // a rank's slice of a point-range split takes the window size of the whole MSM: measured on 1/4 and 1/8 slices of 2^20 points, four in flight,
     // 15-bit windows 0.356 / 0.189 ms per step, 17-bit 0.334 / 0.188 (16-bit at 1/8: 0.182) -- tools/slice_ab.py
@@ -414,9 +572,10 @@ int add_srs(const uint64_t* host_ptr, size_t n, uint32_t* d_srs, bool auto_regis
             if (rc) {
                 // no room for the window tables (a shared GPU): the points stay resident and the MSMs over them take one bucket set per window --
                 // slower (1.8 ms instead of 1.14 at 2^20) but on the GPU, instead of failing the registration and sending the caller to the host
-                for (auto& o : e.segs) (void)hipFree(o.d_tab_alloc);
+                for (auto& o : e.segs) (void)dev_free(o.d_tab_alloc);
                 e.segs.clear();
                 (void)hipGetLastError();
+                fault_absorbed();
                 fprintf(stderr, "bbgpu: window tables of %zu bytes for an SRS of %zu points could not be built (%s): continuing without them\n",
                         (size_t)(twe - twb) * n * 64, n, g_err);
                 g_err[0] = 0;
@@ -577,11 +736,11 @@ int issue_ticket(int t, const SrsEntry& e, size_t off, const uint64_t* const* d_
     MsmSlot* H = h >= 0 ? &g_ctx.slot[h] : nullptr;
     if (H) {
         if (int rc = ensure_slot_stream(*H)) return rc;
-        if (st != S.stream) { // the caller's stream carries the producer of the scalars: the helper's stream starts behind what is enqueued there now
-            if (!g_ctx.helper_dep[h]) CHK(hipEventCreateWithFlags(&g_ctx.helper_dep[h], hipEventDisableTiming));
-            CHK(hipEventRecord(g_ctx.helper_dep[h], st));
-            CHK(hipStreamWaitEvent(H->stream, g_ctx.helper_dep[h], 0));
-        }
+        // `st` carries the producer of the scalars -- a caller's kernel, or the asynchronous upload host_to_device() queued on the slot's OWN stream
+        // (bbgpu_msm_g1 / _batch): the helper's stream starts behind what is enqueued there now, whichever stream that is
+        if (!g_ctx.helper_dep[h]) CHK(hipEventCreateWithFlags(&g_ctx.helper_dep[h], hipEventDisableTiming));
+        CHK(hipEventRecord(g_ctx.helper_dep[h], st));
+        CHK(hipStreamWaitEvent(H->stream, g_ctx.helper_dep[h], 0));
         H->helper = -1;
     }
     int issued[2] = { 0, 0 };
@@ -653,31 +812,60 @@ bool contents_match(SrsEntry& e, size_t off, const uint64_t* points, size_t n)
     return true;
 }
 
+// EXACT mode: every row of the range against the fingerprints taken at upload, spread over the staging pool's threads (64 B read per point:
+// 2^16 points ~0.05 ms, 2^20 ~1 ms on the boxes' hosts -- which is why the callers run it AFTER they have issued the call's kernels, beside them)
+bool contents_match_full(const SrsEntry& e, size_t off, const uint64_t* points, size_t n)
+{
+    if (e.row_hash.size() != e.n) return false;
+    struct Job { const uint64_t* p; const uint64_t* h; std::atomic<int> bad; } job{ points, e.row_hash.data() + off, { 0 } };
+    g_copy_pool.for_range(n, (size_t)1 << 14, [](void* c, size_t lo, size_t hi) {
+        Job* j = static_cast<Job*>(c);
+        uint64_t diff = 0;
+        for (size_t i = lo; i < hi; i++) diff |= hash_row(j->p + i * 16) ^ j->h[i];
+        if (diff) j->bad.store(1);
+    }, &job);
+    return job.bad.load() == 0;
+}
+
 // table lookup by host address, VALIDATED by content: returns entry index and point offset, or -1.  An auto-registered table whose
 // address range matches but whose contents do not (the caller freed the table and another landed there, or refilled the buffer) is
 // evicted; an explicitly registered one is merely not served (its handle stays valid for the device-pointer entries; in-place mutation
 // of a registered table requires bbgpu_srs_release, see bbgpu.h).  Newest entries first.
-int find_srs(const uint64_t* points, size_t n, size_t* offset)
+// deferred_full (optional): set when the entry is in EXACT mode and the caller takes over the full check (contents_match_full, run beside the
+// kernels it has issued; a mismatch there = srs_mark_stale + redo); without it the full check runs here.
+int find_srs(const uint64_t* points, size_t n, size_t* offset, bool* deferred_full = nullptr)
 {
+    if (deferred_full) *deferred_full = false;
     for (size_t k = g_ctx.srs.size(); k-- > 0;) {
         SrsEntry& e = g_ctx.srs[k];
-        if (!e.live || !e.host_ptr) continue;
+        if (!e.live || !e.host_ptr || e.stale_for_host) continue;
         const uint8_t* b = (const uint8_t*)e.host_ptr;
         const uint8_t* p = (const uint8_t*)points;
         if (p < b || p >= b + e.n * 128) continue;
         const size_t d = (size_t)(p - b);
         if (d % 128) continue;
         if (d / 128 + n > e.n) continue;
-        if (!contents_match(e, d / 128, points, n)) {
+        if (!contents_match(e, d / 128, points, n) || (e.validate_full && !deferred_full && !contents_match_full(e, d / 128, points, n))) {
             if (trace_srs()) fprintf(stderr, "bbgpu srs: contents of %p (+%zu rows, n=%zu) differ from the resident copy\n", (const void*)e.host_ptr, d / 128, n);
             if (e.auto_registered) free_entry(e);
+            else if (e.validate_full) e.stale_for_host = true;
             continue;
         }
+        if (deferred_full) *deferred_full = e.validate_full;
         e.last_use = ++g_ctx.use_clock;
         *offset = d / 128;
         return (int)k;
     }
     return -1;
+}
+
+// the deferred full check of an exact-mode entry failed: never serve this copy to a host-pointer call again
+void srs_mark_stale(int idx)
+{
+    SrsEntry& e = g_ctx.srs[idx];
+    if (trace_srs()) fprintf(stderr, "bbgpu srs: full check: contents of %p differ from the resident copy\n", (const void*)e.host_ptr);
+    if (e.auto_registered) free_entry(e);
+    else e.stale_for_host = true;
 }
 
 int log2_exact(size_t n)
@@ -691,8 +879,20 @@ int log2_exact(size_t n)
 // plain: `points` is an n-entry table of plain affine points (64 bytes apart) instead of the 2n-entry endomorphism table -- the argument of
 // the reference's pippenger_low_memory / pippenger_precomputed (scalar_multiplication.cpp:142-262, :478-574).  Such a table is used once and
 // forgotten (no address-keyed cache: these are test / bench entries of the reference, not the prover's).
+int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12], bool plain, bool* stale);
 int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12], bool plain = false)
 {
+    // EXACT cache mode: the call runs against the resident copy while the host re-hashes every row of the caller's table; if they differ the
+    // copy is dropped and the call runs once more, now uploading the table as it is (the reference reads the caller's points on every call,
+    // scalar_multiplication.cpp:604-617)
+    bool stale = false;
+    int rc = msm_host_ptrs_once(scalars, points, n, out, plain, &stale);
+    if (stale) rc = msm_host_ptrs_once(scalars, points, n, out, plain, &stale);
+    return rc;
+}
+int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t out[12], bool plain, bool* stale)
+{
+    *stale = false;
     if (n == 0) {
         host::g1_to_normalised(host::g1_infinity(), out);
         return BBGPU_OK;
@@ -702,7 +902,8 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         return BBGPU_ERR_ARG;
     }
     size_t off = 0;
-    int idx = plain ? -1 : find_srs(points, n, &off);
+    bool full_check = false;
+    int idx = plain ? -1 : find_srs(points, n, &off, &full_check);
     read_host_env();
     if (idx < 0 && n <= (size_t)g_ctx.host_msm_max) { // the verifier's ~20 freshly built points: no allocation, no launch
         host::g1_to_normalised(host::msm_small(scalars, points, n, plain ? 8 : 16), out);
@@ -756,7 +957,7 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         PointPiece pc[MAX_POINT_PIECES];
         const int np = split_pieces(e, off, n, pc, MAX_POINT_PIECES);
         if (np < 0) {
-            if (is_transient) (void)hipFree(transient.d_srs);
+            if (is_transient) (void)dev_free(transient.d_srs);
             set_error("MSM of %zu points spans more than %d table segments", n, MAX_POINT_PIECES);
             return BBGPU_ERR_SIZE;
         }
@@ -798,6 +999,13 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         if (rc == BBGPU_OK) rc = issue_on_entry(sl[w], e, off + ranges[k].o, *stage[w], ranges[k].len, 0, entry_windows(e, ranges[k].len), S.stream);
         if (rc == BBGPU_OK) issued = k + 1;
     }
+    // exact mode: every row of the caller's table against the fingerprints of the resident copy, on the host while the kernels issued above run
+    if (rc == BBGPU_OK && full_check && !contents_match_full(g_ctx.srs[idx], off, points, n)) {
+        for (int k = 0; k < ns; k++) drain_ticket(sl[k]);
+        srs_mark_stale(idx);
+        *stale = true;
+        return BBGPU_OK;
+    }
     while (rc == BBGPU_OK && finished < issued) rc = finish(finished);
     if (rc != BBGPU_OK) { // drain whatever is still in flight so that the slots are usable again (the error text is the first failure's)
         char keep[sizeof(g_err)];
@@ -805,7 +1013,7 @@ int msm_host_ptrs(const uint64_t* scalars, const uint64_t* points, size_t n, uin
         for (int k = 0; k < ns; k++) drain_ticket(sl[k]);
         memcpy(g_err, keep, sizeof(keep));
     }
-    if (is_transient) (void)hipFree(transient.d_srs); // the finishes have waited for the kernels
+    if (is_transient) (void)dev_free(transient.d_srs); // the finishes have waited for the kernels
     if (rc) return rc;
     host::g1_to_normalised(res, out);
     return BBGPU_OK;
@@ -862,25 +1070,28 @@ void bbgpu_shutdown(void)
     (void)hipDeviceSynchronize();
     host_stage_release();
     g_ctx.poly_scratch.release();
-    if (g_ctx.d_poly_tmp) (void)hipFree(g_ctx.d_poly_tmp);
+    if (g_ctx.d_poly_tmp) (void)dev_free(g_ctx.d_poly_tmp);
     g_ctx.d_poly_tmp = nullptr;
     g_ctx.poly_tmp_cap = 0;
     for (auto& e : g_ctx.srs) {
-        if (e.live && e.d_srs) (void)hipFree(e.d_srs);
+        if (e.live && e.d_srs) (void)dev_free(e.d_srs);
         if (e.live)
             for (auto& sg : e.segs)
-                if (sg.d_tab_alloc) (void)hipFree(sg.d_tab_alloc);
+                if (sg.d_tab_alloc) (void)dev_free(sg.d_tab_alloc);
     }
     g_ctx.srs.clear();
     for (auto& sl : g_ctx.slot) sl.release();
-    if (g_ctx.d_stage) (void)hipFree(g_ctx.d_stage);
-    if (g_ctx.d_stage2) (void)hipFree(g_ctx.d_stage2);
+    if (g_ctx.d_stage) (void)dev_free(g_ctx.d_stage);
+    if (g_ctx.d_stage2) (void)dev_free(g_ctx.d_stage2);
     g_ctx.d_stage2 = nullptr;
     g_ctx.stage2_cap = 0;
-    if (g_ctx.d_scratch) (void)hipFree(g_ctx.d_scratch);
+    if (g_ctx.d_scratch) (void)dev_free(g_ctx.d_scratch);
     g_ctx.d_stage = g_ctx.d_scratch = nullptr;
     g_ctx.stage_cap = g_ctx.scratch_cap = 0;
     ntt_release_tables();
+    if (g_ctx.shared_done) (void)hipEventDestroy(g_ctx.shared_done);
+    g_ctx.shared_done = nullptr;
+    g_ctx.shared_used = false;
     (void)hipStreamDestroy(g_ctx.stream);
     g_ctx.stream = nullptr;
     g_ctx.ready = false;
@@ -911,6 +1122,37 @@ int bbgpu_memory_stats(bbgpu_memory_info* out)
     out->staging_bytes = g_ctx.stage_cap + g_ctx.stage2_cap + g_ctx.scratch_cap + g_ctx.poly_tmp_cap + g_ctx.poly_scratch.cap;
     for (int k = 0; k < Context::HOST_RING; k++)
         if (g_ctx.h_stage[k]) out->pinned_host_bytes += Context::HOST_CHUNK;
+    return BBGPU_OK;
+}
+
+int bbgpu_fault_inject(const char* spec)
+{
+    if (fault_set(spec)) {
+        set_error("fault spec '%s' not understood (alloc:k | h2d:k | d2h:k | launch:k)", spec ? spec : "");
+        return BBGPU_ERR_ARG;
+    }
+    return BBGPU_OK;
+}
+int bbgpu_fault_stats(bbgpu_fault_info* out)
+{
+    if (!out) return BBGPU_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    FaultState& F = fault();
+    memset(out, 0, sizeof(*out));
+    out->alloc_calls = F.calls[F_ALLOC].load();
+    out->h2d_calls = F.calls[F_H2D].load();
+    out->d2h_calls = F.calls[F_D2H].load();
+    out->launch_checks = F.calls[F_LAUNCH].load();
+    out->armed = F.armed_kind.load() >= 0 ? 1 : 0;
+    out->fired = F.fired.load();
+    out->absorbed = F.absorbed.load();
+    {
+        std::lock_guard<std::mutex> lf(F.mu);
+        out->live_allocations = F.live.size();
+        out->live_bytes = F.live_bytes;
+    }
+    for (const auto& sl : g_ctx.slot)
+        if (sl.pending) out->slots_pending++;
     return BBGPU_OK;
 }
 
@@ -949,7 +1191,10 @@ int bbgpu_ntt_device(uint64_t* d_coeffs, size_t n, int kind, const uint64_t* con
     rc = ntt_device(d_coeffs, g_ctx.d_scratch, lg, kind, constant, st);
     if (rc == BBGPU_OK) rc = shared_end(st);
     if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^28)", lg);
-    if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc == BBGPU_ERR_HIP) {
+        const hipError_t he = hipGetLastError(); // hipSuccess: the failing call has already described itself (launch_check / dev_malloc)
+        if (he != hipSuccess) set_error("NTT launch failed: %s", hipGetErrorString(he));
+    }
     return rc;
 }
 
@@ -974,7 +1219,10 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
     rc = ntt_device_batch(d_coeffs, stride_elems, batch, g_ctx.d_scratch, lg, kind, constant, st);
     if (rc == BBGPU_OK) rc = shared_end(st);
     if (rc == BBGPU_ERR_SIZE) set_error("NTT size 2^%d unsupported (max 2^28)", lg);
-    if (rc == BBGPU_ERR_HIP) set_error("NTT launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc == BBGPU_ERR_HIP) {
+        const hipError_t he = hipGetLastError(); // hipSuccess: the failing call has already described itself (launch_check / dev_malloc)
+        if (he != hipSuccess) set_error("NTT launch failed: %s", hipGetErrorString(he));
+    }
     return rc;
 }
 
@@ -996,8 +1244,10 @@ int bbgpu_ntt(uint64_t* coeffs, size_t n, int kind, const uint64_t* constant)
     if ((rc = host_to_device(g_ctx.d_stage, coeffs, n * 32, g_ctx.stream)) != BBGPU_OK) return rc;
     rc = bbgpu_ntt_device(g_ctx.d_stage, n, kind, constant, g_ctx.stream);
     if (rc) return rc;
-    // up to here `coeffs` is untouched; a failure while the result is copied back may leave it half overwritten
-    return device_to_host_sync(coeffs, g_ctx.d_stage, n * 32, g_ctx.stream) == BBGPU_OK ? BBGPU_OK : BBGPU_ERR_LOST;
+    // up to here `coeffs` is untouched; a failure while the result is copied back may leave it half overwritten -- LOST only if a byte of it was written
+    bool touched = false;
+    rc = device_to_host_sync(coeffs, g_ctx.d_stage, n * 32, g_ctx.stream, &touched);
+    return rc == BBGPU_OK ? BBGPU_OK : (touched ? BBGPU_ERR_LOST : rc);
 }
 
 /* ---- resident polynomial helpers ---- */
@@ -1119,9 +1369,12 @@ static int stage_in(const uint64_t* host, size_t n)
     if (rc) return rc;
     return host_to_device(g_ctx.d_stage, host, n * 32, g_ctx.stream);
 }
-static int stage_out(uint64_t* host, const uint64_t* dev, size_t n)
+// in_place: the destination is also the call's input -- a failure after any byte of it was written is BBGPU_ERR_LOST (nothing left to fall back on)
+static int stage_out(uint64_t* host, const uint64_t* dev, size_t n, bool in_place = false)
 {
-    return device_to_host_sync(host, dev, n * 32, g_ctx.stream);
+    bool touched = false;
+    const int rc = device_to_host_sync(host, dev, n * 32, g_ctx.stream, &touched);
+    return (rc != BBGPU_OK && in_place && touched) ? BBGPU_ERR_LOST : rc;
 }
 
 int bbgpu_fr_evaluate(const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4])
@@ -1143,7 +1396,8 @@ int bbgpu_kate_opening(const uint64_t* src, uint64_t* dest, size_t n, const uint
     if ((rc = stage_in(src, n)) != BBGPU_OK) return rc;
     if ((rc = grow(&g_ctx.d_stage2, &g_ctx.stage2_cap, n * 32)) != BBGPU_OK) return rc;
     if ((rc = bbgpu_kate_opening_device(g_ctx.d_stage, g_ctx.d_stage2, n, z, f_of_z, g_ctx.stream)) != BBGPU_OK) return rc;
-    return stage_out(dest, g_ctx.d_stage2, n);
+    // the reference calls it in place (polynomial.cpp:327 passes coefficients, coefficients): then a half-written dest is a half-destroyed src
+    return stage_out(dest, g_ctx.d_stage2, n, dest == src);
 }
 
 int bbgpu_lagrange_l1_fft(uint64_t* l_1, size_t n_src, size_t n_target)
@@ -1165,7 +1419,7 @@ int bbgpu_divide_by_pseudo_vanishing(uint64_t* coeffs, size_t n_src, size_t n_ta
     if (!coeffs) return BBGPU_ERR_ARG;
     if ((rc = stage_in(coeffs, n_target)) != BBGPU_OK) return rc;
     if ((rc = bbgpu_divide_by_pseudo_vanishing_device(g_ctx.d_stage, n_src, n_target, g_ctx.stream)) != BBGPU_OK) return rc;
-    return stage_out(coeffs, g_ctx.d_stage, n_target) == BBGPU_OK ? BBGPU_OK : BBGPU_ERR_LOST; // in place, as in bbgpu_ntt
+    return stage_out(coeffs, g_ctx.d_stage, n_target, true); // in place, as in bbgpu_ntt
 }
 
 // polynomial_arithmetic::get_lagrange_evaluations (polynomial_arithmetic.cpp:594-626): {Z_H*(z), L_1(z), L_{n-1}(z)}; host arithmetic
@@ -1424,6 +1678,18 @@ int bbgpu_transcript_write(const char* path, const uint64_t* points_endo_table, 
     return BBGPU_OK;
 }
 
+int bbgpu_srs_set_validate(int srs_handle, int full)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (srs_handle == -1) {
+        g_ctx.srs_validate_full = full != 0;
+        return BBGPU_OK;
+    }
+    if (srs_handle < 0 || srs_handle >= (int)g_ctx.srs.size() || !g_ctx.srs[srs_handle].live) return BBGPU_ERR_ARG;
+    g_ctx.srs[srs_handle].validate_full = full != 0;
+    return BBGPU_OK;
+}
+
 int bbgpu_srs_release(int handle)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -1507,9 +1773,18 @@ void bbgpu_set_host_thresholds(int msm_max_points, int ntt_max_elements)
     g_ctx.host_ntt_max = ntt_max_elements < 0 ? 0 : std::min(64, ntt_max_elements);
 }
 
+static int msm_g1_batch_once(bbgpu_msm_job* jobs, size_t num_jobs, bool* stale);
 int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bool stale = false; // exact cache mode: a resident table turned out to differ from the caller's memory -- dropped; the batch runs once more on a fresh upload
+    int rc = msm_g1_batch_once(jobs, num_jobs, &stale);
+    if (stale) rc = msm_g1_batch_once(jobs, num_jobs, &stale);
+    return rc;
+}
+static int msm_g1_batch_once(bbgpu_msm_job* jobs, size_t num_jobs, bool* stale)
+{
+    *stale = false;
     int rc = BBGPU_OK;
     if (num_jobs == 0) return BBGPU_OK;
     if (!jobs) return BBGPU_ERR_ARG;
@@ -1542,6 +1817,8 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
     size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
     auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const bool tr = trace_srs();
+    struct FullCheck { int idx; size_t off; const uint64_t* points; };
+    std::vector<FullCheck> to_check;
     auto issue = [&](size_t i) -> int {
         const double q0 = tr ? now_ms() : 0;
         const int t = (int)(i & 1);
@@ -1551,13 +1828,19 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
             return BBGPU_ERR_ARG;
         }
         size_t off = 0;
-        int idx = find_srs(jobs[i].points, n, &off);
+        bool full_check = false;
+        int idx = find_srs(jobs[i].points, n, &off, &full_check);
         if (idx < 0) {
             uint32_t* d = nullptr;
             int r = srs_upload(jobs[i].points, n, &d, g_ctx.stream);
             if (r) return r;
             idx = add_srs(jobs[i].points, n, d, true);
             if (idx < 0) return idx;
+        }
+        if (full_check) { // exact mode: checked in full once per distinct range of the batch, after the last job is issued (beside the kernels)
+            bool known = false;
+            for (const auto& c : to_check) known = known || (c.idx == idx && c.off == off);
+            if (!known) to_check.push_back(FullCheck{ idx, off, jobs[i].points });
         }
         const double q1 = tr ? now_ms() : 0;
         int r = grow(stage[t], cap[t], n * 32);
@@ -1583,6 +1866,19 @@ int bbgpu_msm_g1_batch(bbgpu_msm_job* jobs, size_t num_jobs)
         if (tr) fprintf(stderr, "bbgpu batch: job %zu issue %.3f ms, finish(prev) %.3f ms\n", i, t1 - t0, now_ms() - t1);
     }
     const double t2 = tr ? now_ms() : 0;
+    if (rc == BBGPU_OK) {
+        bool bad = false;
+        for (const auto& c : to_check)
+            if (g_ctx.srs[c.idx].live && !contents_match_full(g_ctx.srs[c.idx], c.off, c.points, n)) {
+                srs_mark_stale(c.idx);
+                bad = true;
+            }
+        if (bad) { // outputs already written came from the stale copy: the rerun overwrites every one of them
+            for (int k = 0; k < 2; k++) drain_ticket(sl[k]);
+            *stale = true;
+            return BBGPU_OK;
+        }
+    }
     if (rc == BBGPU_OK) rc = finish(num_jobs - 1);
     if (tr) fprintf(stderr, "bbgpu batch: last finish %.3f ms\n", now_ms() - t2);
     if (rc != BBGPU_OK) { // nothing of this call stays in flight (the error text is the first failure's)

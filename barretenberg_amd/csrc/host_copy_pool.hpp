@@ -34,6 +34,7 @@ public:
         const size_t part = ((bytes / parts) + 4095) & ~(size_t)4095; // page-sized pieces
         {
             std::lock_guard<std::mutex> lk(mu_);
+            fn_ = nullptr;
             dst_ = (char*)dst;
             src_ = (const char*)src;
             bytes_ = bytes;
@@ -46,6 +47,34 @@ public:
         // the helpers' parts are short (< 1 ms): spin, then yield
         for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins)
             if (spins > 2000) std::this_thread::yield();
+    }
+    // fn(lo, hi) over disjoint pieces of [0, items), the caller's thread taking the first piece; returns when every piece is done.
+    // ctx/fn are plain pointers (no allocation on this path).  Used for the full content check of a cached point table (capi.hip).
+    typedef void (*RangeFn)(void* ctx, size_t lo, size_t hi);
+    void for_range(size_t items, size_t min_parallel, RangeFn fn, void* ctx)
+    {
+        const int helpers = items >= min_parallel ? ensure_started() : 0;
+        if (helpers == 0) {
+            fn(ctx, 0, items);
+            return;
+        }
+        const size_t parts = (size_t)helpers + 1;
+        const size_t part = (items + parts - 1) / parts;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = fn;
+            ctx_ = ctx;
+            bytes_ = items;
+            part_ = part;
+            pending_ = helpers;
+            ++generation_;
+        }
+        cv_.notify_all();
+        fn(ctx, 0, std::min(part, items));
+        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins)
+            if (spins > 2000) std::this_thread::yield();
+        std::lock_guard<std::mutex> lk(mu_);
+        fn_ = nullptr;
     }
     void shutdown()
     {
@@ -90,13 +119,19 @@ private:
             char* dst;
             const char* src;
             size_t bytes, part;
+            RangeFn fn;
+            void* ctx;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return generation_ != seen; });
                 seen = generation_;
                 if (stop_) return;
-                dst = dst_; src = src_; bytes = bytes_; part = part_;
+                dst = dst_; src = src_; bytes = bytes_; part = part_; fn = fn_; ctx = ctx_;
             }
+            if (fn) {
+                const size_t lo = idx * part;
+                if (lo < bytes) fn(ctx, lo, std::min(lo + part, bytes));
+            } else
             run_part(idx, dst, src, bytes, part);
             pending_.fetch_sub(1, std::memory_order_release);
         }
@@ -109,6 +144,8 @@ private:
     char* dst_ = nullptr;
     const char* src_ = nullptr;
     size_t bytes_ = 0, part_ = 0;
+    RangeFn fn_ = nullptr; // null: the job is a memcpy of bytes_ bytes in part_-sized pieces; else fn_(ctx_, lo, hi) over [0, bytes_) items
+    void* ctx_ = nullptr;
     std::atomic<int> pending_{ 0 };
 };
 

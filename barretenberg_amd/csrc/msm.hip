@@ -1714,16 +1714,16 @@ size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
 int MsmWorkspace::ensure(size_t bytes)
 {
     if (bytes <= cap) return BBGPU_OK;
-    if (base) (void)hipFree(base);
+    if (base) (void)dev_free(base);
     base = nullptr;
     cap = 0;
-    HIPCHK(hipMalloc((void**)&base, bytes));
+    HIPCHK(dev_malloc((void**)&base, bytes));
     cap = bytes;
     return BBGPU_OK;
 }
 void MsmWorkspace::release()
 {
-    if (base) (void)hipFree(base);
+    if (base) (void)dev_free(base);
     if (h_out) (void)hipHostFree(h_out);
     base = nullptr;
     h_out = nullptr;
@@ -2045,7 +2045,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     }
     if (!fold) HIPCHK(hipMemcpyAsync((uint32_t*)ws.h_out + (size_t)PC.hout_group * 64 * 32, texp, (size_t)G * 64 * 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(S.done, st)); // re-recorded by every piece: the event of the last one covers them all (one stream)
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     S.npieces++;
     S.pending = true;
     return BBGPU_OK;
@@ -2159,46 +2159,39 @@ void MsmSlot::release()
 // stride_bytes: 128 = the reference's 2n-entry endomorphism table (base points at the even entries), 64 = a plain n-entry point table
 int srs_upload(const uint64_t* host_table, size_t n, uint32_t** d_srs_out, hipStream_t st, size_t stride_bytes)
 {
-    uint32_t* d_tab = nullptr;
-    uint32_t* d_srs = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tab, n * stride_bytes));
-    HIPCHK(hipMalloc((void**)&d_srs, n * 64));
-    if (int rc = host_to_device(d_tab, host_table, n * stride_bytes, st)) {
-        (void)hipFree(d_tab);
-        (void)hipFree(d_srs);
-        return rc;
-    }
-    srs_convert_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_tab, d_srs, (uint32_t)n, (uint32_t)(stride_bytes / 4));
-    HIPCHK(hipGetLastError());
+    DevBuf tab, srs; // freed on every error path (dev_free waits for the device: a kernel still reading them has finished by then)
+    HIPCHK(dev_malloc(&tab.p, n * stride_bytes));
+    HIPCHK(dev_malloc(&srs.p, n * 64));
+    if (int rc = host_to_device(tab.p, host_table, n * stride_bytes, st)) return rc;
+    srs_convert_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(tab.as<uint32_t>(), srs.as<uint32_t>(), (uint32_t)n, (uint32_t)(stride_bytes / 4));
+    HIPCHK(launch_check());
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipFree(d_tab));
-    *d_srs_out = d_srs;
+    *d_srs_out = srs.release<uint32_t>();
     return BBGPU_OK;
 }
 
 // builds the pre-shifted window tables for a resident SRS of n points: W x n x 64 bytes
-// windows [w_begin, w_end) only; *d_alloc_out is what hipFree takes, *d_tab_out the (virtual) address of window 0
+// windows [w_begin, w_end) only; *d_alloc_out is what dev_free takes, *d_tab_out the (virtual) address of window 0
 int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, int w_begin, int w_end, uint32_t** d_alloc_out, uint32_t** d_tab_out, hipStream_t st)
 {
-    uint32_t* d_alloc = nullptr;
-    HIPCHK(hipMalloc((void**)&d_alloc, (size_t)(w_end - w_begin) * n * 64));
-    uint32_t* d_tab = d_alloc - (size_t)w_begin * n * 16;
+    DevBuf alloc;
+    HIPCHK(dev_malloc(&alloc.p, (size_t)(w_end - w_begin) * n * 64));
+    uint32_t* d_tab = alloc.as<uint32_t>() - (size_t)w_begin * n * 16;
     srs_table_kernel<<<(uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(d_srs, d_tab, (uint32_t)n, make_layout(c, true), (uint32_t)num_windows,
                                                                                           (uint32_t)w_begin, (uint32_t)w_end);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     HIPCHK(hipStreamSynchronize(st));
-    *d_alloc_out = d_alloc;
+    *d_alloc_out = alloc.release<uint32_t>();
     *d_tab_out = d_tab;
     return BBGPU_OK;
 }
 
 int srs_generate(const uint64_t* x_mont256, size_t first, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st)
 {
-    uint32_t* d_tab = nullptr;
-    uint32_t* d_srs = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tab, 32 * 256 * 128));
-    HIPCHK(hipMalloc((void**)&d_srs, n * 64));
-    srs_gen_table_kernel<<<1, 32, 0, st>>>(d_tab);
+    DevBuf tab, srs;
+    HIPCHK(dev_malloc(&tab.p, 32 * 256 * 128));
+    HIPCHK(dev_malloc(&srs.p, n * 64));
+    srs_gen_table_kernel<<<1, 32, 0, st>>>(tab.as<uint32_t>());
     // x: Montgomery 2^256 -> 2^261
     uint32_t w[8];
     for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)x_mont256[i]; w[2 * i + 1] = (uint32_t)(x_mont256[i] >> 32); }
@@ -2208,21 +2201,17 @@ int srs_generate(const uint64_t* x_mont256, size_t first, size_t n, uint32_t** d
     Fe<Fr, 1, 6> xc = unpack<Fr>(cw);
     Limbs9 xl;
     for (int i = 0; i < NL; i++) xl.d[i] = xc.d[i];
-    srs_gen_points_kernel<<<(uint32_t)((n + 63) / 64), 64, 0, st>>>(d_tab, xl, d_srs, (uint32_t)n, (uint32_t)first);
-    HIPCHK(hipGetLastError());
+    srs_gen_points_kernel<<<(uint32_t)((n + 63) / 64), 64, 0, st>>>(tab.as<uint32_t>(), xl, srs.as<uint32_t>(), (uint32_t)n, (uint32_t)first);
+    HIPCHK(launch_check());
     if (host_table_out) {
-        uint32_t* d_exp = nullptr;
-        HIPCHK(hipMalloc((void**)&d_exp, n * 128));
-        srs_export_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_srs, d_exp, (uint32_t)n);
-        if (int rc = device_to_host_sync(host_table_out, d_exp, n * 128, st)) {
-            (void)hipFree(d_exp);
-            return rc;
-        }
-        HIPCHK(hipFree(d_exp));
+        DevBuf exp;
+        HIPCHK(dev_malloc(&exp.p, n * 128));
+        srs_export_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(srs.as<uint32_t>(), exp.as<uint32_t>(), (uint32_t)n);
+        HIPCHK(launch_check());
+        if (int rc = device_to_host_sync(host_table_out, exp.p, n * 128, st)) return rc;
     }
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipFree(d_tab));
-    *d_srs_out = d_srs;
+    *d_srs_out = srs.release<uint32_t>();
     return BBGPU_OK;
 }
 

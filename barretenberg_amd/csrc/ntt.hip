@@ -80,6 +80,9 @@ __device__ __forceinline__ void store8(uint32_t* p, const uint32_t (&w)[8])
 constexpr int TW_WORDS = 12;
 __device__ __forceinline__ FeT<Fr> load_tw(const uint32_t* table, uint32_t idx)
 {
+#ifdef BBGPU_NTT_ABL_TW // timing ablation (WRONG results; a build variant like BBGPU_NTT_DEBUG_SKIP): every lane reads entry (idx & mask) -- 0: one line per load
+    idx &= BBGPU_NTT_ABL_TW;
+#endif
     const uint4* q = reinterpret_cast<const uint4*>(table + TW_WORDS * (size_t)idx);
     const uint4 a = q[0], b = q[1], c = q[2];
     FeT<Fr> r;
@@ -378,6 +381,14 @@ __device__ __forceinline__ Radix4Out radix4_lazy(const FrS& x0, const FrS& x1, c
     return o;
 }
 
+// orders a wave's LDS accesses among themselves (no instruction: the LDS runs one wave's instructions in issue order; the fences stop the compiler)
+__device__ __forceinline__ void ntt_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 #ifndef NTT_OCC_ATTR
 #define NTT_OCC_ATTR // A/B knob: e.g. -DNTT_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(5,5)))'
 #endif
@@ -479,6 +490,13 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
                 lds[l * E + e3] = y3.d[l];
             }
         }
+        // The 64 groups of a wave in stage pair (s, s + 1) are an aligned block of 2^(s + 2) * (64 >> s) = 256 elements as long as s <= 6 (lds_pos keeps
+        // such blocks), the SAME block in every such pair: between two of them only the wave's own LDS writes have to be visible to it -- the LDS
+        // executes a wave's instructions in order -- and the workgroup's other waves may run ahead or behind (round 5; -DBBGPU_NTT_WG_BARRIERS: A/B).
+#ifndef BBGPU_NTT_WG_BARRIERS
+        if (s + 2 < last_s && s + 2 <= 6) ntt_wave_sync();
+        else
+#endif
         __syncthreads();
     }
 
@@ -630,7 +648,7 @@ size_t table_cap() // read when a new table set is built (rare), so a long-lived
 DomainTables* g_building = nullptr; // the set whose allocations are being accounted (build_domain runs under g_mu)
 hipError_t table_malloc(void** out, size_t bytes)
 {
-    hipError_t e = hipMalloc(out, bytes);
+    hipError_t e = dev_malloc(out, bytes);
     if (e == hipSuccess && g_building) g_building->bytes += bytes;
     return e;
 }
@@ -640,7 +658,7 @@ hipError_t pow_table(uint32_t** out, uint32_t count, const H& base, const H& fac
     hipError_t e = table_malloc((void**)out, (size_t)count * TW_WORDS * 4);
     if (e != hipSuccess) return e;
     ntt_pow_table_kernel<<<(count + 127) / 128, 128, 0, st>>>(*out, count, to_limbs(base), to_limbs(factor));
-    return hipGetLastError();
+    return launch_check();
 }
 
 // one multiplication per element for the inter-pass twist (a table as large as the vector) instead of two (two sqrt(n)-sized tables); BBGPU_NTT_FULL_TWIST=0: A/B
@@ -695,7 +713,7 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
             const uint32_t n = 1u << log2n;
             if ((e = table_malloc((void**)&D->twist_full[inv], (size_t)n * 32)) != hipSuccess) return e;
             ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->twist_full[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n, nullptr, 0u);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = launch_check()) != hipSuccess) return e;
         }
     }
     // coset scale tables: [0] g^i ; [1] g^-i * n^-1   (generator 5: fr.hpp:66-74)
@@ -716,17 +734,17 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
             uint32_t *gb = nullptr, *gk = nullptr; // g^b, b < n2 and g^-k n^-1, k < n1: folded into the coset twist tables, then dropped
             const size_t before_tmp = D->bytes;
             if ((e = pow_table(&gb, 1u << D->log_s2, g, one, st)) != hipSuccess) return e;
-            if ((e = pow_table(&gk, 1u << D->log_s1, gi, ninv, st)) != hipSuccess) { (void)hipFree(gb); return e; }
+            if ((e = pow_table(&gk, 1u << D->log_s1, gi, ninv, st)) != hipSuccess) { (void)dev_free(gb); return e; }
             const size_t tmp_bytes = D->bytes - before_tmp;
             for (int inv = 0; inv < 2 && e == hipSuccess; inv++) {
                 if ((e = table_malloc((void**)&D->coset_twist[inv], (size_t)n * 32)) != hipSuccess) break;
                 ntt_twist_full_kernel<<<(n + 255) / 256, 256, 0, st>>>(D->coset_twist[inv], D->twist_lo[inv], D->twist_hi[inv], (uint32_t)D->lo_bits, (uint32_t)D->log_s2, n,
                                                                        inv ? gk : gb, (uint32_t)inv);
-                e = hipGetLastError();
+                e = launch_check();
             }
             (void)hipStreamSynchronize(st);
-            (void)hipFree(gb);
-            (void)hipFree(gk);
+            (void)dev_free(gb);
+            (void)dev_free(gk);
             D->bytes -= tmp_bytes;
             if (e != hipSuccess) return e;
         }
@@ -739,15 +757,15 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
 void free_domain(DomainTables* D)
 {
     for (int i = 0; i < 2; i++) {
-        for (int p = 0; p < 2; p++) if (D->tw_sub[i][p]) (void)hipFree(D->tw_sub[i][p]);
-        if (D->tw_sub3[i]) (void)hipFree(D->tw_sub3[i]);
-        if (D->twist_lo[i]) (void)hipFree(D->twist_lo[i]);
-        if (D->twist_hi[i]) (void)hipFree(D->twist_hi[i]);
-        if (D->twist_full[i]) (void)hipFree(D->twist_full[i]);
-        if (D->coset_row[i]) (void)hipFree(D->coset_row[i]);
-        if (D->coset_twist[i]) (void)hipFree(D->coset_twist[i]);
-        if (D->scale_lo[i]) (void)hipFree(D->scale_lo[i]);
-        if (D->scale_hi[i]) (void)hipFree(D->scale_hi[i]);
+        for (int p = 0; p < 2; p++) if (D->tw_sub[i][p]) (void)dev_free(D->tw_sub[i][p]);
+        if (D->tw_sub3[i]) (void)dev_free(D->tw_sub3[i]);
+        if (D->twist_lo[i]) (void)dev_free(D->twist_lo[i]);
+        if (D->twist_hi[i]) (void)dev_free(D->twist_hi[i]);
+        if (D->twist_full[i]) (void)dev_free(D->twist_full[i]);
+        if (D->coset_row[i]) (void)dev_free(D->coset_row[i]);
+        if (D->coset_twist[i]) (void)dev_free(D->coset_twist[i]);
+        if (D->scale_lo[i]) (void)dev_free(D->scale_lo[i]);
+        if (D->scale_hi[i]) (void)dev_free(D->scale_hi[i]);
     }
     delete D;
 }
@@ -833,15 +851,18 @@ template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st
         B.store_b_fast = (A.out_sb == 1 && A.cols > 1) ? 1u : 0u;
         if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) // double tile: one workgroup of 1024 threads per CU (144 KiB of LDS), rows twice as wide
             ntt_pass_fused_kernel<FLAGS, 2 * NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), 2 * NTT_THREADS, (size_t)8 * NTT_THREADS * NL * 4, st>>>(B);
-        else if (A.half_tile && (size_t)A.cols * S <= (size_t)NTT_LDS_ELEMS / 2) // half tile: four workgroups of 256 threads per CU
-            ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS / 2, (size_t)2 * NTT_THREADS * NL * 4, st>>>(B);
+        else if (A.half_tile && (size_t)A.cols * S <= (size_t)NTT_LDS_ELEMS / 2) { // half tile: four workgroups of 256 threads per CU
+            // BBGPU_NTT_LDS_PAD (tuning experiment): bytes of LDS requested on top of the tile, e.g. 36864 keeps TWO half-tile workgroups per CU (two waves per SIMD)
+            static const size_t pad = [] { const char* e = getenv("BBGPU_NTT_LDS_PAD"); return e ? std::min<size_t>((size_t)2 * NTT_THREADS * NL * 4, (size_t)strtoull(e, nullptr, 0)) : (size_t)0; }(); // tuning experiment: extra LDS bytes per half-tile workgroup (36864 = two workgroups per CU)
+            ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS / 2, (size_t)2 * NTT_THREADS * NL * 4 + pad, st>>>(B);
+        }
         else
             ntt_pass_fused_kernel<FLAGS, NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, (size_t)4 * NTT_THREADS * NL * 4, st>>>(B);
     } else {
         if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) return hipErrorInvalidValue; // the double tile exists in the fused kernel only
         ntt_pass_kernel<FLAGS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(A);
     }
-    return hipGetLastError();
+    return launch_check();
 }
 
 hipError_t dispatch(int flags, const NttPassArgs& A, hipStream_t st)

@@ -124,7 +124,7 @@ class PlonkProver {
     void release()
     {
         if (st) (void)hipStreamSynchronize(st);
-        for (void* p : allocs) (void)hipFree(p);
+        for (void* p : allocs) (void)dev_free(p);
         allocs.clear();
         if (h_slots) (void)hipHostFree(h_slots);
         h_slots = nullptr;
@@ -138,7 +138,7 @@ class PlonkProver {
     }
     template <class T> int dalloc(T** p, size_t bytes)
     {
-        HIPCHK(hipMalloc((void**)p, bytes));
+        HIPCHK(dev_malloc((void**)p, bytes));
         allocs.push_back(*p);
         return BBGPU_OK;
     }

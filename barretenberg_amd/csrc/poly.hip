@@ -718,16 +718,16 @@ PowTab make_powtab(const host::Fr& base)
 int Scratch::ensure(size_t bytes)
 {
     if (bytes <= cap) return BBGPU_OK;
-    if (base) (void)hipFree(base);
+    if (base) (void)dev_free(base);
     base = nullptr;
     cap = 0;
-    HIPCHK(hipMalloc((void**)&base, bytes));
+    HIPCHK(dev_malloc((void**)&base, bytes));
     cap = bytes;
     return BBGPU_OK;
 }
 void Scratch::release()
 {
-    if (base) (void)hipFree(base);
+    if (base) (void)dev_free(base);
     if (h_pinned) (void)hipHostFree(h_pinned);
     base = nullptr;
     h_pinned = nullptr;
@@ -744,32 +744,32 @@ int powers(uint64_t* d_out, size_t n, const host::Fr& base, const host::Fr& star
     const uint32_t blocks = strided_blocks(n);
     k_powers<<<blocks, PT, 0, st>>>((uint32_t*)d_out, (uint32_t)n, make_powtab(base), host::limbs_m256(start),
                                    host::limbs_m261(host::fr_pow(base, (uint64_t)blocks * PT)));
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 int copy_pad(uint64_t* d_dst, const uint64_t* d_src, size_t n_src, size_t n_dst, hipStream_t st)
 {
     k_copy_pad<<<pw_blocks(n_dst), PT, 0, st>>>((uint32_t*)d_dst, (const uint32_t*)d_src, (uint32_t)n_src, (uint32_t)n_dst);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 int add_inplace(uint64_t* d_a, const uint64_t* d_b, size_t n, hipStream_t st)
 {
     k_add_inplace<<<pw_blocks(n), PT, 0, st>>>((uint32_t*)d_a, (const uint32_t*)d_b, (uint32_t)n);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 int mul_pointwise(uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n, hipStream_t st)
 {
     k_mul<<<pw_blocks(n), PT, 0, st>>>((uint32_t*)d_out, (const uint32_t*)d_a, (const uint32_t*)d_b, (uint32_t)n);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 int mul2c(uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n, const host::Fr& c, hipStream_t st)
 {
     const host::Fr cf = host::fr_mul(c, host::fr_from_u64(32)); // c * 2^5: the FIX2 factor folded in
     k_mul2c<<<pw_blocks(n), PT, 0, st>>>((uint32_t*)d_out, (const uint32_t*)d_a, (const uint32_t*)d_b, (uint32_t)n, host::limbs_m261(cf));
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -933,7 +933,7 @@ static int scan_pair_at(int mode, const ScanJob* jobs, int count, uint8_t* base,
         k_scan_phase3<1><<<gb, SCAN_T, 0, st>>>(B[0], B[1]);
         if (any_out) k_scan_phase3<1><<<g1, SCAN_T, 0, st>>>(A3[0], A3[1]);
     }
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     for (int j = 0; j < count; j++)
         if (jobs[j].d_total && jobs[j].n) HIPCHK(hipMemcpyAsync(jobs[j].d_total, B[j].bpart, 32, hipMemcpyDeviceToDevice, st));
     return BBGPU_OK;
@@ -977,7 +977,7 @@ int evaluate_to_device(const uint64_t* d_coeffs, size_t n, const host::Fr& z, ui
     const uint32_t nt = blocks * PT;
     k_eval_partial<<<blocks, PT, 0, st>>>((const uint32_t*)d_coeffs, (uint32_t)n, make_powtab(z), host::limbs_m261(host::fr_pow(z, nt)), (uint32_t*)S.base);
     k_sum_small<<<1, PT, 0, st>>>((const uint32_t*)S.base, blocks, (uint32_t*)d_result);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 int evaluate(const uint64_t* d_coeffs, size_t n, const host::Fr& z, host::Fr* out, Scratch& S, hipStream_t st)
@@ -1021,7 +1021,7 @@ int evaluate_batch_to_device(const EvalJob* jobs, int count, const host::Fr z[2]
     }
     k_eval_partial_batch<<<dim3(maxb, count), PT, 0, st>>>(A);
     k_sum_small_batch<<<count, PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1054,7 +1054,7 @@ int sigma_from_mapping(uint64_t* d_out, const uint32_t* d_mapping, const uint64_
 {
     k_sigma_from_mapping<<<pw_blocks(n), PT, 0, st>>>((uint32_t*)d_out, d_mapping, (const uint32_t*)d_roots, (uint32_t)n,
                                                      host::limbs_m261(host::fr_from_limbs(FrHostP::GEN5)), host::limbs_m261(host::fr_from_limbs(FrHostP::GEN7)));
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1069,7 +1069,7 @@ int z_terms(ZTermsArgs A, const host::Fr& root, const host::Fr& beta, const host
     A.beta_k2_m256 = host::limbs_m256(host::fr_mul(beta, host::fr_from_limbs(FrHostP::GEN7)));
     A.gamma_m256 = host::limbs_m256(gamma);
     k_z_terms<<<blocks, PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1077,7 +1077,7 @@ int sigma_prepare(uint64_t* d_dst, const uint64_t* d_sigma, const uint64_t* d_w,
 {
     k_sigma_prepare<<<pw_blocks(n_dst), PT, 0, st>>>((uint32_t*)d_dst, (const uint32_t*)d_sigma, (const uint32_t*)d_w, (uint32_t)n, (uint32_t)n_dst,
                                                     host::limbs_m256(gamma));
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1092,7 +1092,7 @@ int quotient_large(QuotLargeArgs A, const host::Fr& root4n, const host::Fr& beta
     A.beta_k2_m256 = host::limbs_m256(host::fr_mul(beta, host::fr_from_limbs(FrHostP::GEN7)));
     A.gamma_m256 = host::limbs_m256(gamma);
     k_quotient_large<<<blocks, PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1106,7 +1106,7 @@ int quotient_mid(QuotMidArgs A, const host::Fr& alpha, const host::Fr& alpha_bas
     A.abase_fix2_m261 = host::limbs_m261(host::fr_mul(alpha_base, f2));
     A.abase_fix3_m261 = host::limbs_m261(host::fr_mul(alpha_base, f3));
     k_quotient_mid<<<pw_blocks(A.n2), PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1115,7 +1115,7 @@ int quotient_mimc(QuotMimcArgs A, const host::Fr& alpha_base, const host::Fr& al
     A.alpha_m261 = host::limbs_m261(alpha_step);
     A.abase_fix_m261 = host::limbs_m261(host::fr_mul(alpha_base, host::fr_from_u64(32)));
     k_quotient_mimc<<<pw_blocks(A.n4), PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1123,7 +1123,7 @@ int quotient_seq(QuotSeqArgs A, const host::Fr& c, hipStream_t st)
 {
     A.c_fix_m261 = host::limbs_m261(host::fr_mul(c, host::fr_from_u64(32)));
     k_quotient_seq<<<pw_blocks(A.n2), PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1134,7 +1134,7 @@ int quotient_bool(QuotBoolArgs A, const host::Fr& c_left, const host::Fr& c_righ
     A.cr_fix_m261 = host::limbs_m261(host::fr_mul(c_right, f2));
     A.co_fix_m261 = host::limbs_m261(host::fr_mul(c_out, f2));
     k_quotient_bool<<<pw_blocks(A.n2), PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1172,7 +1172,7 @@ int divide_by_pseudo_vanishing(uint64_t* d_coeffs, int log2n, int log2N, hipStre
     const uint32_t blocks = strided_blocks(N);
     k_divide_vanishing<<<blocks, PT, 0, st>>>((uint32_t*)d_coeffs, (uint32_t)N, k, make_powtab(rootN), host::limbs_m261(host::fr_from_limbs(FrHostP::GEN5)),
                                              host::limbs_m261(host::fr_pow(rootN, (uint64_t)blocks * PT)), host::limbs_m261(wninv), inv[0], inv[1], inv[2], inv[3]);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1190,7 +1190,7 @@ int lagrange_l1_fft(uint64_t* d_l1, uint64_t* d_tmp, int log2n, int log2N, Scrat
     const uint32_t blocks = strided_blocks(N);
     k_l1_denominators<<<blocks, PT, 0, st>>>((uint32_t*)d_l1, (uint32_t)N, make_powtab(rootN), host::limbs_m256(host::fr_from_limbs(FrHostP::GEN5)),
                                             host::limbs_m261(host::fr_pow(rootN, (uint64_t)blocks * PT)));
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     int rc = batch_invert(d_l1, d_tmp, N, S, st);
     if (rc) return rc;
     // numerators ((g w)^n - 1) / n: k values
@@ -1206,7 +1206,7 @@ int lagrange_l1_fft(uint64_t* d_l1, uint64_t* d_tmp, int log2n, int log2N, Scrat
         s[j] = host::limbs_m261(v);
     }
     k_l1_scale<<<pw_blocks(N), PT, 0, st>>>((uint32_t*)d_l1, (uint32_t)N, k, s[0], s[1], s[2], s[3]);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
@@ -1214,7 +1214,7 @@ int lincomb(LinCombArgs A, const host::Fr* coeffs, hipStream_t st)
 {
     for (int j = 0; j < A.count; j++) A.c[j] = host::limbs_m261(coeffs[j]);
     k_lincomb<<<pw_blocks(A.n), PT, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 

@@ -72,6 +72,29 @@ typedef struct {
 } bbgpu_memory_info;
 int bbgpu_memory_stats(bbgpu_memory_info* out);
 
+/* ---- the error contract on a machine that HAS a GPU: fault injection (testing) ---------------------------------------
+ * The reference API has no error channel (assert.hpp:19-23 compiles to nothing, scalar_multiplication.cpp:680-684 prints and returns), so a GPU call
+ * that fails in the middle of a proof must leave the library usable and the shim able to answer on the host (SURVEY 8b "Errors").  Every device
+ * allocation, every copy of a caller's buffer and every launch check of the library passes one of four host-side funnels; a spec
+ *     "alloc:k" | "h2d:k" | "d2h:k" | "launch:k"          (k = 0: the next such call)
+ * makes the k-th call of that kind -- counted from the moment the spec is set -- fail ONCE with the error a real failure of that kind returns
+ * (out of memory / invalid value / launch failure) without touching the device.  The environment variable BBGPU_FAIL_AT holds the same spec for
+ * programs that cannot call this (read once, at the library's first allocation / copy / launch).  NULL or "" disarms.  No kernel reads any of it.
+ * bbgpu_fault_stats: how often each funnel was passed since the spec was set, whether the armed failure fired, how many failures the library rode
+ * out by itself (an SRS kept without its window tables), the library's live device allocations (count and bytes: after bbgpu_shutdown() both
+ * are 0 unless an error path leaked) and the MSM slots still in flight. */
+typedef struct {
+    uint64_t alloc_calls, h2d_calls, d2h_calls, launch_checks;
+    uint64_t armed;            /* 1 while a failure is armed and has not fired yet */
+    uint64_t fired;            /* failures injected since the spec was set (0 or 1) */
+    uint64_t absorbed;         /* failures the library continued after WITHOUT returning an error (degraded, still on the GPU) */
+    uint64_t live_allocations; /* device allocations of the library that are live now */
+    uint64_t live_bytes;
+    uint64_t slots_pending;    /* MSM slots with work in flight or a result not yet collected */
+} bbgpu_fault_info;
+int bbgpu_fault_inject(const char* spec);
+int bbgpu_fault_stats(bbgpu_fault_info* out);
+
 /* ---- NTT ---------------------------------------------------------------------------------------------------------
  * Drop-in for polynomial_arithmetic::{fft,ifft,coset_fft,coset_ifft,fft_with_constant,ifft_with_constant,
  * coset_fft_with_constant}(fr::field_t* coeffs, const evaluation_domain& domain[, const fr::field_t& constant]):
@@ -107,6 +130,16 @@ int bbgpu_ntt_device_batch(uint64_t* d_coeffs, size_t n, size_t stride_elems, in
  * memory).  A table registered EXPLICITLY keeps its handle until bbgpu_srs_release: mutate it in place only after releasing it
  * (host-pointer calls stop being served from a handle whose contents changed, device-pointer calls by handle cannot notice). */
 int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
+/* EXACT mode for the address-keyed cache (the reference reads the caller's points on every call, scalar_multiplication.cpp:604-617): with
+ * full != 0 every host-pointer MSM (bbgpu_msm_g1, bbgpu_msm_g1_batch and the shim entries above them) served from this table re-hashes EVERY row of
+ * the range it uses against the fingerprints taken at upload -- on the host, spread over the staging threads, while the call's kernels already run
+ * against the resident copy; if a single row differs the copy is dropped (a table registered on first sight is evicted, an explicitly registered one
+ * stops serving host-pointer calls; its handle stays valid) and the call runs once more on a fresh upload: identical inputs -> identical outputs on
+ * the very next call, whatever part of the table was rewritten.  srs_handle -1 sets the default for tables registered from now on (on first sight
+ * or explicitly); the environment variable BBGPU_SRS_VALIDATE=full does the same at start-up.  Cost (tools/boundary_ab.py, profiles/r05_boundary_ab.txt)
+ * is printed there for 2^16 and 2^20 points; the default stays the 16-row sample because the full check of a 2^20-point table reads 64 MiB of host
+ * memory per call. */
+int bbgpu_srs_set_validate(int srs_handle, int full);
 /* Registration also builds, on the device, the pre-shifted window tables 2^(c w) * P_i (the reference's
  * generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129): W x n x 64 bytes (1 GiB at n = 2^20), so that
  * all digit windows share one bucket set.  On by default from 1024 points on; bbgpu_set_precompute(0) turns it off for

@@ -25,6 +25,7 @@
 //   that the composer folds into one gate with a q_o_next term, boolean constraints; the proof then carries w_o_shifted_eval
 //   plonk_gpu adapter <num_gates>              the level-2 integration of INTEGRATION.md: reference composer -> bbgpu_plonk_* resident prover
 //                                              -> reference Verifier; prints the proof in the `prove` format (GPU-linked builds only)
+//   plonk_gpu_full faults <num_gates> <kind> [first [step]]   the error contract under injected GPU failures (see faults() below)
 //   plonk_xxx verify <num_gates> < proof       rebuild the same circuit's Verifier and check a proof given in the `prove` text
 //                                              format on stdin (used to verify proofs made by the native GPU prover)
 #include <barretenberg/curves/bn254/fq.hpp>
@@ -69,6 +70,13 @@ extern "C" void bbshim_profile_reset(void);
 extern "C" void bbshim_profile_write(const char* tag, double caller_ms);
 #pragma weak bbshim_profile_reset
 #pragma weak bbshim_profile_write
+// faults mode (below): the shim's count of calls answered on the host, the library's fault injection and accounting
+extern "C" unsigned long long bbshim_fallback_calls(void);
+#pragma weak bbshim_fallback_calls
+#pragma weak bbgpu_fault_inject
+#pragma weak bbgpu_fault_stats
+#pragma weak bbgpu_shutdown
+#pragma weak bbgpu_memory_stats
 
 namespace {
 // the synthetic SRS secret (fixed, public: this is a test SRS)
@@ -477,10 +485,88 @@ int verify(size_t num_gates)
     printf("verified %d\n", ok ? 1 : 0);
     return ok ? 0 : 2;
 }
+
+// ---- the error contract of the drop-in boundary under INJECTED GPU failures (GPU-linked builds, no BBGPU_SHIM_STRICT) -------------------------
+// plonk_gpu_full faults <num_gates> <kind> [first [step]]     kind = alloc | h2d | d2h | launch (include/bbgpu.h, bbgpu_fault_inject)
+// Prints the healthy proof in the `prove` format, then counts how often a COLD proof (library shut down before it: every table, workspace and
+// staging buffer is allocated again) passes the funnel of <kind> -- N -- and, for k = first, first + step, ... < N: shuts the library down, arms
+// "<kind>:k", proves (the k-th allocation / copy / launch check of that proof fails; the shim must answer on the host and carry on), proves once
+// more with nothing armed, and prints one line
+//   fault <kind> <k> fired F absorbed A fallbacks_failed_proof X fallbacks_next_proof Y proof_same P next_same Q verified V pending S mem_same M
+// mem_same compares bbgpu_memory_stats() after the second proof with the same point of the healthy run; the last line is the library's live
+// device allocations after a final bbgpu_shutdown() (0 unless an error path leaked).  A d2h failure inside an in-place call is BBGPU_ERR_LOST and
+// aborts by design (bb_shim.cpp): `d2h` sweeps are for seeing exactly that from the outside.
+struct ProofBytes {
+    unsigned char b[9 * 64 + 12 * 32];
+    bool ok;
+};
+ProofBytes prove_once(size_t num_gates)
+{
+    std::unique_ptr<waffle::ComposerBase> composer = make_circuit(num_gates);
+    waffle::Prover prover = composer->preprocess();
+    waffle::Verifier verifier = waffle::preprocess(prover);
+    waffle::plonk_proof proof = prover.construct_proof();
+    ProofBytes r;
+    memset(&r, 0, sizeof r);
+    memcpy(r.b, &proof.W_L, 9 * 64);
+    memcpy(r.b + 9 * 64, &proof.w_l_eval, 7 * 32); // the evaluations the standard arithmetic circuit fills (waffle_types.hpp:30-36)
+    r.ok = verifier.verify_proof(proof);
+    return r;
+}
+int faults(size_t num_gates, const char* kind, size_t first, size_t step)
+{
+    if (!bbgpu_fault_inject || !bbgpu_fault_stats || !bbshim_fallback_calls || !bbgpu_shutdown || !bbgpu_memory_stats) {
+        fprintf(stderr, "faults: this build is not linked against libbbgpu.so / libbbshim.so\n");
+        return 5;
+    }
+    if (int rc = prove(num_gates, false)) return rc; // the healthy proof, in full: the caller compares it with the golden proof
+    const ProofBytes good = prove_once(num_gates);
+    char spec[64];
+    // healthy cold run: funnel count of this kind in one proof, memory after two proofs
+    bbgpu_shutdown();
+    snprintf(spec, sizeof spec, "%s:%llu", kind, ~0ULL >> 1);
+    if (bbgpu_fault_inject(spec)) return 6;
+    (void)prove_once(num_gates);
+    bbgpu_fault_info fi;
+    bbgpu_fault_stats(&fi);
+    const uint64_t N = !strcmp(kind, "alloc") ? fi.alloc_calls : !strcmp(kind, "h2d") ? fi.h2d_calls : !strcmp(kind, "d2h") ? fi.d2h_calls : fi.launch_checks;
+    (void)prove_once(num_gates);
+    bbgpu_memory_info m0;
+    bbgpu_memory_stats(&m0);
+    printf("sites %s %llu\n", kind, (unsigned long long)N);
+    for (uint64_t k = first; k < N; k += step ? step : 1) {
+        bbgpu_shutdown();
+        snprintf(spec, sizeof spec, "%s:%llu", kind, (unsigned long long)k);
+        bbgpu_fault_inject(spec);
+        const unsigned long long f0 = bbshim_fallback_calls();
+        const ProofBytes p1 = prove_once(num_gates);
+        const unsigned long long f1 = bbshim_fallback_calls();
+        bbgpu_fault_stats(&fi);
+        const ProofBytes p2 = prove_once(num_gates);
+        const unsigned long long f2 = bbshim_fallback_calls();
+        bbgpu_fault_info fj;
+        bbgpu_fault_stats(&fj);
+        bbgpu_memory_info m1;
+        bbgpu_memory_stats(&m1);
+        // an SRS that lost its window tables to the injected failure stays without them (absorbed: slower, still on the GPU): its bytes differ by design
+        if (fi.absorbed) { m1.srs_table_bytes = m0.srs_table_bytes; m1.srs_auto_bytes = m0.srs_auto_bytes; }
+        printf("fault %s %llu fired %llu absorbed %llu fallbacks_failed_proof %llu fallbacks_next_proof %llu proof_same %d next_same %d verified %d pending %llu mem_same %d\n", kind,
+               (unsigned long long)k, (unsigned long long)fi.fired, (unsigned long long)fi.absorbed, f1 - f0, f2 - f1, !memcmp(p1.b, good.b, sizeof good.b),
+               !memcmp(p2.b, good.b, sizeof good.b), (int)(p1.ok && p2.ok), (unsigned long long)fj.slots_pending, !memcmp(&m0, &m1, sizeof m0));
+        fflush(stdout);
+    }
+    bbgpu_shutdown();
+    bbgpu_fault_inject(nullptr);
+    bbgpu_fault_stats(&fi);
+    printf("live_after_shutdown %llu allocations %llu bytes\n", (unsigned long long)fi.live_allocations, (unsigned long long)fi.live_bytes);
+    return 0;
+}
 } // namespace
 
 int main(int argc, char** argv)
 {
+    if (argc >= 4 && !strcmp(argv[1], "faults"))
+        return faults((size_t)atol(argv[2]), argv[3], argc >= 5 ? (size_t)atol(argv[4]) : 0, argc >= 6 ? (size_t)atol(argv[5]) : 1);
     if (argc >= 4 && !strcmp(argv[1], "transcript")) return write_transcript(argv[2], (size_t)atol(argv[3]));
     if (argc >= 3 && !strcmp(argv[1], "prove")) return prove((size_t)atol(argv[2]), false);
     if (argc >= 3 && !strcmp(argv[1], "trace")) return prove((size_t)atol(argv[2]), true);

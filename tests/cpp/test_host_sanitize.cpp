@@ -155,6 +155,35 @@ int main()
         pool.copy(small_dst, small_src, sizeof small_src); // below the parallel threshold: the caller's thread alone
         CHECK(!memcmp(small_dst, small_src, sizeof small_src), "copy pool: small copy");
     }
+    // ---- round 5: range jobs (CopyPool::for_range -- the full content check of a cached point table) interleaved with copies on one pool
+    {
+        CopyPool pool;
+        struct Ctx { const uint32_t* v; std::atomic<unsigned long long> sum; } ctx{ nullptr, { 0 } };
+        for (int rep = 0; rep < 8; rep++) {
+            const size_t items = 100000 + 977 * (size_t)rep;
+            std::vector<uint32_t> v(items);
+            unsigned long long want = 0;
+            for (size_t i = 0; i < items; i++) { v[i] = (uint32_t)(i * 2654435761u + (unsigned)rep); want += v[i]; }
+            ctx.v = v.data();
+            ctx.sum = 0;
+            pool.for_range(items, 1024, [](void* c, size_t lo, size_t hi) {
+                Ctx* x = static_cast<Ctx*>(c);
+                unsigned long long s = 0;
+                for (size_t i = lo; i < hi; i++) s += x->v[i];
+                x->sum += s;
+            }, &ctx);
+            CHECK(ctx.sum.load() == want, "copy pool range job %d", rep);
+            std::vector<unsigned char> src((size_t)1 << 20, (unsigned char)rep), dst((size_t)1 << 20, 0);
+            pool.copy(dst.data(), src.data(), src.size()); // a copy right behind a range job: the helpers must not run the stale function
+            CHECK(!memcmp(dst.data(), src.data(), src.size()), "copy after a range job %d", rep);
+            if (rep == 4) pool.shutdown();
+        }
+        ctx.sum = 0;
+        const uint32_t few[3] = { 1, 2, 3 };
+        ctx.v = few;
+        pool.for_range(3, 1024, [](void* c, size_t lo, size_t hi) { Ctx* x = static_cast<Ctx*>(c); for (size_t i = lo; i < hi; i++) x->sum += x->v[i]; }, &ctx);
+        CHECK(ctx.sum.load() == 6, "copy pool: small range job on the caller's thread");
+    }
     // ---- round 4: the staging copies are entered from several threads (the resident prover's uploads beside another thread's transform) and take the
     //      library mutex themselves (capi.hip host_to_device / device_to_host_sync); the single-producer pool behind such a guard, two threads at once
     {

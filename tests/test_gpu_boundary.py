@@ -117,6 +117,61 @@ def test_srs_cache_catches_a_rewritten_middle_slice(gpu, oracle, tables):
     assert gpu.srs_cache_stats()[0] == live0
 
 
+def test_exact_cache_mode_sees_one_rewritten_point_on_the_very_next_call(gpu, oracle, golden):
+    """the reference reads the caller's points on every call (scalar_multiplication.cpp:604-617); the address-keyed cache answers from a
+    resident copy after a 16-row sample, so ONE point rewritten in the middle of a cached 2^16-point table is served stale (almost) for ever.  In exact
+    mode (bbgpu_srs_set_validate / BBGPU_SRS_VALIDATE=full) the very next call returns the point the REFERENCE computed for the rewritten table
+    (tests/golden/msm_r5.json `rewrite`, tools/gen_golden_r5.py) -- through pippenger(), through the batched entry, for a table registered on first sight
+    and for an explicitly registered one (whose handle keeps naming what was registered)."""
+    import torch
+    from tests.util import sha
+    g = golden("msm_r5.json")
+    rw = g["rewrite"]
+    n, at, src = rw["n"], rw["index"], rw["takes_point"]
+    h0, table = gpu.srs_generate(limbs(g["srs_secret_mont"]), src + 1, True)  # 2^16 + 6 points of the fixtures' SRS (digest pinned over 2^21 by the parity tests)
+    gpu.srs_release(h0)
+    scalars = oracle.random_scalars(SCALAR_SEED, n)
+
+    def same(out, case):
+        return np.array_equal(out[0:4], limbs(case["x"])) and np.array_equal(out[4:8], limbs(case["y"]))
+    try:  # (a table beyond the module's 12 MiB cache cap is still kept: everything else registered on first sight is evicted for it)
+        # sampled mode (the default): the stale copy survives the next call -- the window the exact mode closes (16 of 65536 rows sampled)
+        buf = aligned_copy(table[:2 * n])
+        assert same(gpu.pippenger(scalars, buf, n), rw["before"])
+        buf[2 * at:2 * at + 2] = table[2 * src:2 * src + 2]
+        assert same(gpu.pippenger(scalars, buf, n), rw["before"])  # stale: identical inputs, not the reference's output
+        # exact mode as the default for tables seen from now on
+        gpu.srs_set_validate(-1, True)
+        buf = aligned_copy(table[:2 * n])  # a new address: registered on first sight, in exact mode
+        assert same(gpu.pippenger(scalars, buf, n), rw["before"])
+        assert same(gpu.pippenger(scalars, buf, n), rw["before"])  # served from the copy (full check passes)
+        buf[2 * at:2 * at + 2] = table[2 * src:2 * src + 2]
+        assert same(gpu.pippenger(scalars, buf, n), rw["after"])   # the very next call
+        assert same(gpu.pippenger(scalars, buf, n), rw["after"])
+        buf[2 * at:2 * at + 2] = table[2 * at:2 * at + 2]          # and back, through the batched entry (two jobs over the same range: one check)
+        outs = gpu.batched_scalar_multiplications([(buf, scalars, n), (buf, scalars, n)])
+        assert same(outs[0], rw["before"]) and same(outs[1], rw["before"])
+        buf[2 * at:2 * at + 2] = table[2 * src:2 * src + 2]
+        outs = gpu.batched_scalar_multiplications([(buf, scalars, n), (buf, scalars, n)])
+        assert same(outs[0], rw["after"]) and same(outs[1], rw["after"])
+        # sub-slices of the (re-uploaded) table are served as before
+        want = oracle.msm_affine(aligned_copy(scalars[:5000]), aligned_copy(buf[2 * (at - 100):2 * (at + 4900)]), 5000)
+        assert np.array_equal(gpu.pippenger(aligned_copy(scalars[:5000]), buf[2 * (at - 100):], 5000)[:8], want[:8])
+        gpu.srs_set_validate(-1, False)
+        # per-handle flag on an explicitly registered table
+        buf2 = aligned_copy(table[:2 * n])
+        h = gpu.srs_register(buf2)
+        gpu.srs_set_validate(h, True)
+        assert same(gpu.pippenger(scalars, buf2, n), rw["before"])
+        buf2[2 * at:2 * at + 2] = table[2 * src:2 * src + 2]
+        assert same(gpu.pippenger(scalars, buf2, n), rw["after"])
+        d = torch.from_numpy(scalars.view(np.int64)).cuda()
+        assert same(gpu.msm_device(h, d.data_ptr(), n), rw["before"])  # the handle still names what was registered
+        gpu.srs_release(h)
+    finally:
+        gpu.srs_set_validate(-1, False)
+
+
 def test_two_transforms_in_flight_on_two_streams(gpu, oracle):
     """back-to-back transforms on different streams used to share one pass-1 scratch buffer"""
     import torch

@@ -664,6 +664,28 @@ def test_msm_beyond_one_table_segment(gpu, oracle, golden):
     gpu.srs_release(h)
 
 
+def test_msm_host_batch_jobs_straddling_a_segment_boundary(gpu, oracle, golden):
+    """batched_scalar_multiplications() (bbgpu_msm_g1_batch) with jobs of 2^19 points that start 2^18 (- 11 k) points before the boundary between the two
+    window-table segments of a 2^21-point SRS: every job runs as two pieces, the second one on a HELPER slot whose stream must wait for the
+    scalars' asynchronous upload on the job's own stream (16 MiB per job, large enough for the digit kernel to overtake the DMA
+    were the dependency missing).  Points the REFERENCE computed for exactly these jobs (tests/golden/msm_r5.json, tools/gen_golden_r5.py)."""
+    g = golden("msm_r5.json")
+    N = 1 << 21
+    h, table = gpu.srs_generate(limbs(g["srs_secret_mont"]), N, True)
+    assert sha(table[0::2]) == g["srs_digest_2097152"]
+    scalars = oracle.random_scalars(SCALAR_SEED, N)
+    cases = g["straddle"]
+    for rounds in range(2):  # the second round finds the staging buffers and the helper's workspace warm: the upload is then the only thing in front of the kernels
+        jobs = [(table[2 * c["offset"]:], aligned_copy(scalars[c["scalars_from"]:c["scalars_from"] + c["n"]]), c["n"]) for c in cases]
+        outs = gpu.batched_scalar_multiplications(jobs)
+        for c, out in zip(cases, outs):
+            _check(out, c)
+    # the same jobs one at a time through pippenger() (two ranges per segment piece at the host entry)
+    c = cases[1]
+    _check(gpu.pippenger(aligned_copy(scalars[c["scalars_from"]:c["scalars_from"] + c["n"]]), table[2 * c["offset"]:], c["n"]), c)
+    gpu.srs_release(h)
+
+
 def test_msm_four_table_segments(gpu, oracle, golden):
     """n = 2^22 and n = 3 * 2^20 + 11 on a 2^22-point SRS (four window-table segments; the ragged size leaves the last one partly used): points the
     REFERENCE computed (tests/golden/big_r4.json, tools/gen_golden_r4b.py), through the device entry, the host-pointer entry and a two-job batch"""
