@@ -280,10 +280,17 @@ Context g_ctx;
 
 void read_host_env()
 {
-    if (g_ctx.host_env_read) return;
+    // the staging knobs are read once per process whatever else happened; the two thresholds only while bbgpu_set_host_thresholds() has not set them
+    // (round 5: that call used to switch off the reading of ALL four variables)
+    static bool staging_read = false;
+    const bool thresholds = !g_ctx.host_env_read;
     g_ctx.host_env_read = true;
-    if (const char* e = getenv("BBGPU_HOST_MSM_MAX")) g_ctx.host_msm_max = atoi(e);
-    if (const char* e = getenv("BBGPU_HOST_NTT_MAX")) g_ctx.host_ntt_max = std::min(64, atoi(e));
+    if (thresholds) {
+        if (const char* e = getenv("BBGPU_HOST_MSM_MAX")) g_ctx.host_msm_max = atoi(e);
+        if (const char* e = getenv("BBGPU_HOST_NTT_MAX")) g_ctx.host_ntt_max = std::min(64, atoi(e));
+    }
+    if (staging_read) return;
+    staging_read = true;
     if (const char* e = getenv("BBGPU_STAGE_MAX_BYTES")) g_ctx.host_stage_max = (size_t)strtoull(e, nullptr, 0);
     if (const char* e = getenv("BBGPU_STAGE_CHUNK_BYTES")) g_ctx.host_chunk = std::min(Context::HOST_CHUNK, std::max((size_t)64 << 10, (size_t)strtoull(e, nullptr, 0))); // tuning knob
 }

@@ -733,8 +733,9 @@ hipError_t build_domain(DomainTables* D, int log2n, hipStream_t st)
             if ((e = pow_table(&D->coset_row[1], 1u << D->log_s2, h_pow2k(gi, D->log_s1), one, st)) != hipSuccess) return e;  // (g^-n1)^k2
             uint32_t *gb = nullptr, *gk = nullptr; // g^b, b < n2 and g^-k n^-1, k < n1: folded into the coset twist tables, then dropped
             const size_t before_tmp = D->bytes;
-            if ((e = pow_table(&gb, 1u << D->log_s2, g, one, st)) != hipSuccess) return e;
-            if ((e = pow_table(&gk, 1u << D->log_s1, gi, ninv, st)) != hipSuccess) { (void)dev_free(gb); return e; }
+            // (a table whose launch check failed is allocated all the same: both temporaries are freed on every way out -- found by the injected launch failures of round 5)
+            if ((e = pow_table(&gb, 1u << D->log_s2, g, one, st)) != hipSuccess) { (void)dev_free(gb); return e; }
+            if ((e = pow_table(&gk, 1u << D->log_s1, gi, ninv, st)) != hipSuccess) { (void)dev_free(gb); (void)dev_free(gk); return e; }
             const size_t tmp_bytes = D->bytes - before_tmp;
             for (int inv = 0; inv < 2 && e == hipSuccess; inv++) {
                 if ((e = table_malloc((void**)&D->coset_twist[inv], (size_t)n * 32)) != hipSuccess) break;

@@ -308,14 +308,28 @@ def plonk_leg(G, args, gates=65536, reps=10):
     return out
 
 
+NTT_RAMP_MS = 120.0  # untimed transforms before the first timed one, see device_ntt_leg
+
+
 def device_ntt_leg(G, dev, d_vec, n, kinds, steps, warmup, barrier):
-    """in-place transforms on a device-resident vector; HIP events on the stream the kernels are launched on"""
+    """in-place transforms on a device-resident vector; HIP events on the stream the kernels are launched on.
+    Like the main leg (run_steps(40) before the W warm-up steps) the leg first leaves the post-idle ramp: after an idle period -- the upload of the
+    vector, the host work before it -- the same transform takes 0.115 ms (2^20) / 0.50 ms (2^22) and falls to 0.099 / 0.43 ms over the next ~40 ms of
+    back-to-back transforms (tools/ntt_ramp.py, profiles/r05_ntt_ramp.txt); W = 5 warm-up transforms are 0.6 ms.  NTT_RAMP_MS of untimed
+    transforms come first, then the W warm-up transforms, then exactly `steps` timed ones."""
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
     torch.cuda.synchronize()
     out = {}
     for kind in kinds:
-        for _ in range(warmup):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(tstream)
+        for _ in range(8):
+            G.ntt_device(d_vec.data_ptr(), n, kind, stream=stream)
+        e1.record(tstream)
+        torch.cuda.synchronize()
+        ramp = int(NTT_RAMP_MS / max(1e-3, e0.elapsed_time(e1) / 8))
+        for _ in range(ramp + warmup):
             G.ntt_device(d_vec.data_ptr(), n, kind, stream=stream)
         barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -326,7 +340,7 @@ def device_ntt_leg(G, dev, d_vec, n, kinds, steps, warmup, barrier):
         e1.record(tstream)
         barrier()
         wall = (time.perf_counter() - t0) / steps
-        out[kind] = {"ms_per_step": wall * 1e3, "elements_per_s": n / wall, "device_ms": e0.elapsed_time(e1) / steps}
+        out[kind] = {"ms_per_step": wall * 1e3, "elements_per_s": n / wall, "device_ms": e0.elapsed_time(e1) / steps, "untimed_ramp_transforms": ramp + 8, "warmup": warmup}
     return out
 
 
