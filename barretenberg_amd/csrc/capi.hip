@@ -752,6 +752,15 @@ int issue_ticket(int t, const SrsEntry& e, size_t off, const uint64_t* const* d_
     }
     int issued[2] = { 0, 0 };
     int rc = BBGPU_OK;
+    // every slot's workspace is sized ONCE, for the largest piece it will carry: (seg / 2, 2 seg + 7) is pieces of seg / 2, seg and seg / 2 + 7 points, and a
+    // workspace grown for the second piece would be freed (dev_free waits for the device) under the first one still queued on the stream
+    {
+        size_t largest[2] = { 0, 0 };
+        for (int k = 0; k < np; k++) largest[(H && (k & 1)) ? 1 : 0] = std::max(largest[(H && (k & 1)) ? 1 : 0], pc[k].len);
+        for (int side = 0; side < 2 && rc == BBGPU_OK; side++)
+            if (largest[side]) rc = (side ? *H : S).ws.ensure(MsmWorkspace::bytes_needed(largest[side], e.tab_c, (we - wb) * jobs));
+        if (rc != BBGPU_OK) return rc;
+    }
     for (int k = 0; k < np && rc == BBGPU_OK; k++) {
         const int side = (H && (k & 1)) ? 1 : 0;
         MsmSlot& T = side ? *H : S;

@@ -1867,7 +1867,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
         set_error("MSM in %d pieces of %u bucket sets: the result array holds %u", S.npieces + 1, G, MSM_HOUT_GROUPS);
         return BBGPU_ERR_SIZE;
     }
-    // (a later piece is never larger than the first: the workspace is not reallocated under a piece still running on the stream)
+    // (capi.hip issue_ticket() sizes the workspace for the LARGEST piece of a multi-piece MSM before piece 0 is issued -- a slice that starts mid-segment has
+    // its largest piece in the middle -- so that this never frees a workspace under a piece still queued on the stream)
     int rc = ws.ensure(MsmWorkspace::bytes_needed(n, c, (int)nw));
     if (rc) return rc;
     if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, (size_t)MSM_HOUT_GROUPS * 64 * 128));

@@ -773,11 +773,11 @@ int bbgpu_plonk_prover_create(const bbgpu_plonk_circuit* c, int srs_handle)
         set_error("MiMC widget selectors: give both q_mimc_selector and q_mimc_coefficient or neither, and not together with the bool or the sequential widget");
         return BBGPU_ERR_ARG;
     }
-    // 2^21: the L_1 polynomial on the 2n coset is a batch inversion = a product scan of 2n elements, and the three-phase scans take 2^22 (poly.hip
-    // scan_pair: one nested level); the largest circuit with a reference proof to compare against is 2^21 gates as well (tests/golden/plonk_proofs.json).
-    // (Round 3 accepted 2^22 here and failed inside construct_proof with "scan of 8388608 elements".)
+    // 2^21: the largest circuit with a REFERENCE proof to compare against (tests/golden/plonk_proofs.json); nothing in the kernels stops there any more -- the
+    // scans nest to 2^28 elements (poly.hip, round 4), the transforms reach 2^28, the commitments run over table segments -- but a proof of a larger circuit
+    // would be parity-unpinned, so the entry refuses it instead of returning bytes no reference ever produced.
     if (c->n < 4 || (c->n & (c->n - 1)) || c->n > ((size_t)1 << 21)) {
-        set_error("circuit size %zu: must be a power of two, 4 <= n <= 2^21 (the resident scans take 2^22 elements, the prover scans 2n)", c->n);
+        set_error("circuit size %zu: must be a power of two, 4 <= n <= 2^21 (the largest size a reference proof exists for: larger proofs would be parity-unpinned)", c->n);
         return BBGPU_ERR_SIZE;
     }
     const int W = bbgpu_srs_num_windows(srs_handle, c->n);

@@ -158,8 +158,25 @@ def pipelined_steps(k, issue, collect, exchange=None, depth=2, clock=None, issue
             clock.add("wait", now() - t0)
         return part
 
+    def abandon(tickets):
+        """a step failed: nothing of this call may stay in flight -- the tickets already issued are collected (their MSM slots would stay pending
+        otherwise), the exchange already started is finished (the peers are inside that collective); the caller then re-raises, and a rank that
+        dies non-zero is what ends the others (bench.py's launcher), since they would wait in the NEXT collective for ever"""
+        nonlocal pending
+        for tk in tickets:
+            try:
+                collect(tk)
+            except Exception:  # noqa: BLE001 -- the first failure is the one reported
+                pass
+        if pending is not None:
+            try:
+                exchange.finish(pending)
+            except Exception:  # noqa: BLE001
+                pass
+            pending = None
+
     if issuer and k > 0:
-        q, room, err = queue.Queue(), threading.Semaphore(depth), []
+        q, room, err, stop = queue.Queue(), threading.Semaphore(depth), [], object()  # `stop`: a ticket may legitimately be None (an empty share)
 
         def run():
             try:
@@ -170,28 +187,45 @@ def pipelined_steps(k, issue, collect, exchange=None, depth=2, clock=None, issue
                     q.put(timed_issue())
             except BaseException as exc:  # noqa: BLE001 -- handed to the collecting thread
                 err.append(exc)
-                q.put(None)
+            q.put(stop)
 
         th = threading.Thread(target=run, name="bbgpu-issuer", daemon=True)
         th.start()
-        for _ in range(k):
-            tk = q.get()
-            if err:
-                break
-            part = timed_collect(tk)
-            room.release()
-            retire(part)
+        try:
+            while True:
+                tk = q.get()  # in issue order: every ticket issued before a failure comes out before the marker
+                if tk is stop:
+                    break
+                try:
+                    part = timed_collect(tk)
+                finally:
+                    room.release()
+                retire(part)
+        except BaseException:
+            th.join()
+            left = []
+            while not q.empty():
+                tk = q.get()
+                if tk is not stop:
+                    left.append(tk)
+            abandon(left)
+            raise
         th.join()
         if err:
+            abandon([])
             raise err[0]
     else:
         inflight = []
-        for _ in range(k):
-            inflight.append(timed_issue())
-            if len(inflight) == depth:
+        try:
+            for _ in range(k):
+                inflight.append(timed_issue())
+                if len(inflight) == depth:
+                    retire(timed_collect(inflight.pop(0)))
+            while inflight:
                 retire(timed_collect(inflight.pop(0)))
-        while inflight:
-            retire(timed_collect(inflight.pop(0)))
+        except BaseException:
+            abandon(inflight)
+            raise
     if exchange is not None:
         flush()
         if pending is not None:

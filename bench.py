@@ -302,10 +302,22 @@ def plonk_leg(G, args, gates=65536, reps=10):
                 out["reference_prover_on_shim"] = {"ms": float(m2.group(1)), "cores": threads, "proof_bit_exact": r2.stdout.strip().split("\n")[:26] == ref_lines[:26],
                                                    "inside_shim_ms": prof and prof.get("inside_shim_ms"), "reference_host_code_ms": prof and (prof["caller_ms"] - prof["inside_shim_ms"]),
                                                    "h2d_bytes": prof and prof.get("h2d_bytes"), "d2h_bytes": prof and prof.get("d2h_bytes"),
-                                                   "note": "third proof of the child process (BB_WARM_PROOFS=2); breakdown per symbol: profiles/r03_shim_profile_2e16.json"}
+                                                   "note": "third proof of the child process (BB_WARM_PROOFS=2); breakdown per symbol of the builder's run: %s" % (os.path.relpath(newest_profile("shim_profile_2e16_third_proof.json") or newest_profile("shim_profile_2e16.json") or "profiles/", ROOT))}
     P.destroy()
     G.srs_release(srs)
     return out
+
+
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the newest round that has one (the committed evidence a live figure is printed beside), or "" """
+    import glob
+    import re
+    best = (-1, "")
+    for q in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)):
+        m = re.match(r"r(\d\d)_", os.path.basename(q))
+        if m and int(m.group(1)) > best[0]:
+            best = (int(m.group(1)), q)
+    return best[1]
 
 
 NTT_RAMP_MS = 120.0  # untimed transforms before the first timed one, see device_ntt_leg
@@ -789,14 +801,15 @@ def main():
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes of the SAME binary (profiles/, tools/pmc_summary.py), corrected by the factor the
         # gather calibration kernel of known traffic gave for this access shape
-        traffic = ntt_traffic = None
+        traffic = ntt_traffic = ntt22_traffic = None
         traffic_source = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % t) for t in ("r04", "r03", "r02")) if os.path.exists(q)), "")
+        tpath = newest_profile("pmc_traffic.json")
         if tpath:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("msm_accumulate_kernel_bytes_per_launch")
                 ntt_traffic = tj.get("ntt_2e20_bytes_per_transform")
+                ntt22_traffic = tj.get("ntt_2e22_bytes_per_transform")
                 # NOT measured in this run: the counter passes need rocprofv3 around the process (tools/collect_profiles.sh); the figure is the committed one
                 traffic_source = "%s (rocprofv3 --pmc passes on the builder's box, tools/collect_profiles.sh; library of that run: %s; this run's library: %s)" % (
                     os.path.relpath(tpath, ROOT), tj.get("library_sha256_16", "not recorded"), lib_sha16())
@@ -804,11 +817,11 @@ def main():
                 traffic = None
         # the same fraction from the committed rocprofv3 trace of this command (profiles/: spacing of consecutive accumulation dispatches'
         # end times, tools/acc_spacing.py), so that the live figure and the profile can be compared without reading profiles/README.md
-        rocprof_spacing_ms = rocprof_frac = None
-        for tag in ("r03", "r02"):
-            sp = os.path.join(ROOT, "profiles", "%s_acc_spacing.txt" % tag)
-            if os.path.exists(sp):
+        rocprof_spacing_ms = rocprof_frac = rocprof_spacing_file = None
+        for sp in (newest_profile("acc_spacing.txt"),):
+            if sp:
                 import re
+                rocprof_spacing_file = os.path.relpath(sp, ROOT)
                 m = re.search(r"spacing[^0-9]*([0-9.]+) ms", open(sp).read())
                 if m:
                     rocprof_spacing_ms = float(m.group(1))
@@ -858,7 +871,7 @@ def main():
                                          "note": "two MSMs in flight, a separate run after the timed region with an event after every stage: stages of consecutive steps overlap, so they sum to more than ms_per_step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": "msm_accumulate_kernel", "kernel_ms": acc_ms, "kernel_ms_events_raw": acc_raw_ms, "kernel_ms_alone": float(stage[3]),
-                         "frac_from_rocprof_spacing": rocprof_frac, "rocprof_spacing_ms": rocprof_spacing_ms,
+                         "frac_from_rocprof_spacing": rocprof_frac, "rocprof_spacing_ms": rocprof_spacing_ms, "rocprof_spacing_source": rocprof_spacing_file,
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md; algorithmic bytes %d per launch" % alg_bytes,
                          "valu": {"bound": "VALU instruction issue of the mixed addition's instruction stream at the measured per-instruction rates",
                                   "floor_ms": issue_floor_ms, "achieved_ms": acc_ms, "frac": issue_floor_ms / acc_ms if acc_ms > 0 else 0.0,
@@ -870,7 +883,7 @@ def main():
         }
         if ntt22 is not None:
             line["ntt_2e22"] = {"metric": "Fr radix-2 NTT elements/s at n=4*2^20 (BASELINE config 3)", "fft": ntt22["fft"], "coset_fft": ntt22["coset_fft"],
-                                "roofline": ntt_roofline(1 << 22, ntt22["fft"]["device_ms"], None)}
+                                "roofline": ntt_roofline(1 << 22, ntt22["fft"]["device_ms"], ntt22_traffic)}
         if config1 is not None:
             line["config1_2e16"] = config1
             line["skewed_2e20"] = skewed

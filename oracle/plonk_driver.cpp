@@ -554,6 +554,12 @@ int faults(size_t num_gates, const char* kind, size_t first, size_t step)
                (unsigned long long)k, (unsigned long long)fi.fired, (unsigned long long)fi.absorbed, f1 - f0, f2 - f1, !memcmp(p1.b, good.b, sizeof good.b),
                !memcmp(p2.b, good.b, sizeof good.b), (int)(p1.ok && p2.ok), (unsigned long long)fj.slots_pending, !memcmp(&m0, &m1, sizeof m0));
         fflush(stdout);
+        if (memcmp(&m0, &m1, sizeof m0)) {
+            const uint64_t *a = (const uint64_t*)&m0, *b = (const uint64_t*)&m1;
+            fprintf(stderr, "faults %s:%llu: bbgpu_memory_stats healthy / after:", kind, (unsigned long long)k);
+            for (size_t i = 0; i < sizeof m0 / 8; i++) fprintf(stderr, " %llu/%llu", (unsigned long long)a[i], (unsigned long long)b[i]);
+            fprintf(stderr, "\n");
+        }
     }
     bbgpu_shutdown();
     bbgpu_fault_inject(nullptr);

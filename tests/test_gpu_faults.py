@@ -217,6 +217,6 @@ def test_reference_prover_on_the_shim_survives_every_injected_failure(golden, ki
         assert row["proof_same"] == 1 and row["next_same"] == 1 and row["verified"] == 1, (k, row)
         assert row["fallbacks_failed_proof"] + row["absorbed"] >= 1, (k, row)  # answered on the host, or ridden out on the GPU
         assert row["fallbacks_next_proof"] == 0, (k, row)                       # the next proof is back on the GPU
-        assert row["pending"] == 0 and row["mem_same"] == 1, (k, row)
+        assert row["pending"] == 0 and row["mem_same"] == 1, (k, row, [x for x in r.stderr.split("\n") if x.startswith("faults ")][:3])
     assert sum(row["fallbacks_failed_proof"] > 0 for row in rows) >= (3 * sites) // 4  # riding out is the exception (an SRS without its window tables)
     assert rest[-1] == "live_after_shutdown 0 allocations 0 bytes", rest[-1]

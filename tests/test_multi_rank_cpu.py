@@ -156,12 +156,17 @@ def _pipeline_worker(rank, world, port, ret):
         if len(issued) == 2:
             raise RuntimeError("issue failed")
         return issue()
-    issued.clear()
-    try:
-        pipelined_steps(steps, bad_issue, collect, None, depth=2, issuer=True)
-        ok = False
-    except RuntimeError:
-        pass
+    # ... and every ticket issued before the failure is still collected (they used to stay in the queue -- MSM slots left pending), with and
+    # without the helper thread, at depths where one or two tickets are waiting when the failure arrives
+    for issuer, depth in ((True, 2), (True, 4), (False, 2), (False, 3)):
+        issued.clear()
+        collected = []
+        try:
+            pipelined_steps(steps, bad_issue, lambda t: (collected.append(t), mul(t + 1))[1], None, depth=depth, issuer=issuer)
+            ok = False
+        except RuntimeError:
+            pass
+        ok = ok and sorted(collected) == issued == [0, 1]
     # world == 1 semantics: no exchange, partial sums come back as they are
     issued.clear()
     solo = pipelined_steps(3, issue, lambda t: mul(t + 1), None)

@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag>        (tag = r02 ...; outputs land in gpurun_out/prof_<tag>/, summaries are copied by hand)
 # Counter passes carry --pmc only (no tracing domains), one counter group per pass, as MI355X_MICROARCH.md prescribes.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -15,6 +15,9 @@ echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fet
 echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH_PMC > $OUT/write.log 2>&1 || exit 1
 echo "== calibration FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- $ROOT/tools/ubench/ubench_traffic > $OUT/cal_fetch.log 2>&1 || exit 1
 echo "== calibration WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $ROOT/tools/ubench/ubench_traffic > $OUT/cal_write.log 2>&1 || exit 1
+echo "== 2^22 transforms FETCH_SIZE / WRITE_SIZE"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/ntt22_fetch -- python3 $ROOT/tools/ntt_only.py 22 > $OUT/ntt22_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/ntt22_write -- python3 $ROOT/tools/ntt_only.py 22 > $OUT/ntt22_write.log 2>&1 || exit 1
 echo "== SQ"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary > $OUT/sq.log 2>&1 || exit 1
 echo "== prover trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/plonk -- python3 $ROOT/tools/plonk_bench.py --reps 10 --no-reference > $OUT/plonk.log 2>&1 || exit 1
 echo "== latency traces"
@@ -25,14 +28,14 @@ python tools/timeline.py $OUT/trace 2 > $OUT/timeline_steady_state.txt
 python tools/window_timeline.py $OUT/plonk 0.7 2700 > $OUT/prover_timeline.txt
 for L in 20 16; do echo "== one 2^$L-point MSM at a time (tools/latency_run.py): start, duration, gap (us), kernel"; python tools/latency_timeline.py $OUT/lat$L; done > $OUT/latency_timeline.txt
 rm -rf $OUT/lat20 $OUT/lat16
-python tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/${TAG}_pmc_traffic.json
+python tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/${TAG}_pmc_traffic.json $OUT/ntt22_fetch $OUT/ntt22_write
 python tools/pmc_sq_summary.py $OUT/sq $OUT/${TAG}_pmc_sq.json
 python tools/acc_spacing.py $OUT/trace | tee $OUT/acc_spacing.txt
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bench_steps10.csv
 cp $(find $OUT/plonk -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_plonk_prover_2e16.csv
 $ROOT/tools/ubench/ubench_traffic > $OUT/ubench_traffic.txt 2>&1
 # keep the merged scratch small: the raw traces of the counter passes are not needed once summarised
-rm -rf $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/sq
+rm -rf $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/sq $OUT/ntt22_fetch $OUT/ntt22_write
 find $OUT/trace $OUT/plonk -name "*kernel_trace.csv" -size +20M -delete
 echo "== shard prediction"
 python tools/shard_sim.py $OUT/${TAG}_shard_prediction.json > $OUT/shard_sim.txt 2>&1; tail -6 $OUT/shard_sim.txt
@@ -52,7 +55,6 @@ python tools/skewed_stages.py > $OUT/skewed_stages.txt 2>&1
 python tools/boundary_ab.py > $OUT/boundary_ab.txt 2>&1
 BBGPU_HOST_MSM_SPLIT=1 python tools/boundary_ab.py >> $OUT/boundary_ab.txt 2>&1
 python tools/acc_ab.py > $OUT/acc_ab.txt 2>&1
-[ -f barretenberg_amd/_variants/libbbgpu_r2.so ] && BBGPU_LIB=$ROOT/barretenberg_amd/_variants/libbbgpu_r2.so python tools/acc_ab.py >> $OUT/acc_ab.txt 2>&1
 $ROOT/tools/ubench/ubench_pcie > $OUT/pcie.txt 2>&1
 export OMP_NUM_THREADS=16
 for w in 0 2; do BB_WARM_PROOFS=$w BBGPU_SHIM_PROFILE=$OUT/shim_profile_w$w.json oracle/_ref/plonk_gpu prove 65536 > /dev/null 2>> $OUT/shim_profile.log; done

@@ -8,7 +8,7 @@ tools/ubench/ubench_traffic runs under the same two passes and gives one factor 
     calib_stream32  32 contiguous bytes per lane in and out                           -> ntt_pass_kernel
     calib_stream16  16 contiguous bytes per lane in and out (the guide's x2 case)     -> everything else (digits, sort, tail)
 
-    python tools/pmc_summary.py <bench_fetch_dir> <bench_write_dir> <calib_fetch_dir> <calib_write_dir> [out.json]
+    python tools/pmc_summary.py <bench_fetch_dir> <bench_write_dir> <calib_fetch_dir> <calib_write_dir> [out.json [<ntt22_fetch_dir> <ntt22_write_dir>]]
 
 bench passes:  rocprofv3 --pmc FETCH_SIZE -d <dir> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary
 calib passes:  rocprofv3 --pmc FETCH_SIZE -d <dir> -- tools/ubench/ubench_traffic        (and the same with WRITE_SIZE)"""
@@ -80,6 +80,13 @@ def main():
     ntt = [v for k, v in kernels.items() if "ntt_pass" in k]
     # bench.py --no-boundary launches 2^20-point transforms only: one transform = one pass-1 launch + one pass-2 launch
     ntt_total = sum(v["total_bytes"] * v["launches"] for v in ntt) / max(1, sum(v["launches"] for v in ntt)) * 2 if ntt else None
+    # optional: the same two passes around tools/ntt_only.py 22 (every ntt_pass launch of that process is a 2^22-point pass)
+    ntt22_total = None
+    if len(sys.argv) > 7:
+        f22, w22 = load(sys.argv[6], "FETCH_SIZE"), load(sys.argv[7], "WRITE_SIZE")
+        ff, wf = calib["calib_stream32"]["fetch_factor"] or 1.0, calib["calib_stream32"]["write_factor"] or 1.0
+        per = [mean(f22.get(k, [])) * ff + mean(w22.get(k, [])) * wf for k in sorted(set(f22) | set(w22)) if "ntt_pass" in k]
+        ntt22_total = sum(per) if len(per) == 2 else None  # one pass-1 kernel + one pass-2 kernel
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing domains) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary; "
                      "calibration: the same two passes -- tools/ubench/ubench_traffic",
            "library_sha256_16": lib_sha16(),
@@ -90,6 +97,8 @@ def main():
            "msm_algorithmic_bytes": (1 << 20) * 96 + 96,
            "ntt_2e20_bytes_per_transform": ntt_total,
            "ntt_2e20_algorithmic_bytes": 2 * 32 * (1 << 20),
+           "ntt_2e22_bytes_per_transform": ntt22_total,
+           "ntt_2e22_algorithmic_bytes": 2 * 32 * (1 << 22),
            "kernels": kernels}
     json.dump(out, open(out_path, "w"), indent=1)
     print("wrote", out_path)
