@@ -945,6 +945,9 @@ int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n
     // long-lived SRS and registered on first sight.
     SrsEntry transient{};
     const bool is_transient = idx < 0 && (plain || n < AUTO_REGISTER_MIN_POINTS);
+    const bool tr = trace_srs();
+    auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double q0 = tr ? now_ms() : 0;
     if (idx < 0) {
         uint32_t* d = nullptr;
         int rc = srs_upload(points, n, &d, g_ctx.stream, plain ? 64 : 128);
@@ -994,6 +997,7 @@ int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n
     }
     size_t max_len = 0;
     for (const auto& r : ranges) max_len = std::max(max_len, r.len);
+    const double q1 = tr ? now_ms() : 0;
     uint64_t** stage[2] = { &g_ctx.d_stage, &g_ctx.d_stage2 };
     size_t* cap[2] = { &g_ctx.stage_cap, &g_ctx.stage2_cap };
     host::Xyzz res = host::g1_infinity();
@@ -1015,6 +1019,7 @@ int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n
         if (rc == BBGPU_OK) rc = issue_on_entry(sl[w], e, off + ranges[k].o, *stage[w], ranges[k].len, 0, entry_windows(e, ranges[k].len), S.stream);
         if (rc == BBGPU_OK) issued = k + 1;
     }
+    const double q2 = tr ? now_ms() : 0;
     // exact mode: every row of the caller's table against the fingerprints of the resident copy, on the host while the kernels issued above run
     if (rc == BBGPU_OK && full_check && !contents_match_full(g_ctx.srs[idx], off, points, n)) {
         for (int k = 0; k < ns; k++) drain_ticket(sl[k]);
@@ -1029,9 +1034,11 @@ int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n
         for (int k = 0; k < ns; k++) drain_ticket(sl[k]);
         memcpy(g_err, keep, sizeof(keep));
     }
+    const double q3 = tr ? now_ms() : 0;
     if (is_transient) (void)dev_free(transient.d_srs); // the finishes have waited for the kernels
     if (rc) return rc;
     host::g1_to_normalised(res, out);
+    if (tr) fprintf(stderr, "bbgpu msm n=%zu: table %.3f, upload + issue %.3f, wait + host sums %.3f, free + normalise %.3f ms\n", n, q1 - q0, q2 - q1, q3 - q2, now_ms() - q3);
     return BBGPU_OK;
 }
 

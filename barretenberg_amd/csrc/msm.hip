@@ -307,9 +307,10 @@ template <class DT> __device__ __forceinline__ void load_digits8(const DT* __res
     }
 }
 template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, DT* __restrict__ digits_all, unsigned long long* __restrict__ signs_all,
-                                                               uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we)
+                                                               uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we, uint32_t* __restrict__ zero_word)
 {
     FRONT_PRIO();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0; // the arrival counter of sortA_scan_fused_kernel, two launches down the stream
     // only windows [wb, we) are stored (a rank of a window-sharded MSM needs its share only); the carry chain still starts at window 0
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -507,6 +508,67 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
         gstart_end[0] = run;
         gstart_end[1] = 0xffffffffu; // sentinel: the accumulation's last lane walks past the last bucket into a dummy one (msm_accumulate_kernel)
     }
+}
+
+// The three kernels above as ONE launch (round 5: a small MSM is a chain of dependent launches of ~5 us each, and these three are nothing but latency --
+// 6.7 + 4.8 + 5.1 us of a 253 us MSM of 2^16 points): one workgroup per group scans its [slices][bins] histogram matrix column by column (thread t owns
+// bin t % bins -- neighbouring lanes read neighbouring words -- and the slices of part t / bins), scans the bin totals in LDS, and the LAST group to
+// arrive (an agent-scope counter the digits kernel zeroed) lays down the window bases.  bins is a power of two <= SORT_THREADS.
+__global__ void __launch_bounds__(SORT_THREADS) sortA_scan_fused_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ binstart, uint32_t* __restrict__ totals,
+                                                                      uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t bins, uint32_t log_bins, uint32_t slices,
+                                                                      uint32_t* __restrict__ arrivals)
+{
+    FRONT_PRIO();
+    __shared__ uint32_t part[SORT_THREADS];
+    __shared__ uint32_t last_flag;
+    const uint32_t wl = blockIdx.x, t = threadIdx.x, G = gridDim.x;
+    const uint32_t bin = t & (bins - 1), p = t >> log_bins, parts = SORT_THREADS >> log_bins;
+    uint32_t* H = histA + (size_t)wl * slices * bins + bin;
+    const uint32_t spp = (slices + parts - 1) / parts, s0 = min(slices, p * spp), s1 = min(slices, s0 + spp);
+    uint32_t sum = 0;
+    for (uint32_t sl = s0; sl < s1; sl++) sum += H[(size_t)sl * bins];
+    part[t] = sum; // [p][bin]
+    __syncthreads();
+    uint32_t before = 0, total = 0; // this bin: entries of the parts before mine, of all parts
+    for (uint32_t q = 0; q < parts; q++) {
+        const uint32_t v = part[(q << log_bins) + bin];
+        before += q < p ? v : 0u;
+        total += v;
+    }
+    uint32_t run = before;
+    for (uint32_t sl = s0; sl < s1; sl++) {
+        const uint32_t cnt = H[(size_t)sl * bins];
+        H[(size_t)sl * bins] = run;
+        run += cnt;
+    }
+    __syncthreads();
+    // exclusive scan of the bin totals (threads [0, bins) hold them)
+    const uint32_t mine = t < bins ? total : 0u;
+    part[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (t < bins) binstart[(size_t)wl * bins + t] = part[t] - mine;
+    if (t == SORT_THREADS - 1) {
+        totals[wl] = part[SORT_THREADS - 1];
+        __threadfence(); // the group's total is visible device-wide before the group counts as arrived
+        last_flag = (atomicAdd(arrivals, 1u) == G - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_flag || t != 0) return;
+    __threadfence(); // acquire: the other groups' totals
+    uint32_t acc = 0;
+    for (uint32_t w = 0; w < G; w++) {
+        bases[w] = acc;
+        acc += __atomic_load_n(&totals[w], __ATOMIC_RELAXED);
+    }
+    bases[G] = acc;
+    gstart_end[0] = acc;
+    gstart_end[1] = 0xffffffffu; // sentinel, as in sort_bases_kernel
 }
 
 template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, const uint32_t* __restrict__ cursorsA,
@@ -1537,6 +1599,8 @@ __global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_final_quad_kernel(const 
 
 int msm_choose_c(size_t n)
 {
+    static const int forced = [] { const char* e = getenv("BBGPU_PLAIN_C"); return e ? std::min((int)MSM_MAX_C, std::max(4, atoi(e))) : 0; }(); // tuning knob: window size of MSMs WITHOUT window tables
+    if (forced) return forced;
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
     int c = lg - 4;
@@ -1929,15 +1993,24 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     ScalarSets sets{};
     for (int j = 0; j < jobs; j++) sets.p[j] = (const uint32_t*)d_scalars_v[j];
     const bool wide = c > 16; // 17-bit windows: signed digits up to +-2^16
-    if (wide) msm_digits_kernel<uint16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (uint16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
-    else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
+    uint32_t* const arrivals = bases + nw + 16; // inside the 512 spare bytes of the `totals` block (carve): zeroed by the digits kernel, counted up by the fused scan
+    if (wide) msm_digits_kernel<uint16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (uint16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we, arrivals);
+    else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we, arrivals);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
     if (wide) sortA_hist_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
     else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
-    sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
-    sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
-    sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
+    // the scans between the two halves of pass A: one launch up to 2^21 entries (a chain of dependent launches is what a small MSM is made of), three wider ones above
+    static const int scan_fused_env = [] { const char* e = getenv("BBGPU_SORT_SCAN_FUSED"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force
+    const bool scan_fused = (sort_bins & (sort_bins - 1)) == 0 && sort_bins <= (uint32_t)SORT_THREADS && G <= 64 &&
+                            (scan_fused_env < 0 ? (uint64_t)n * nw < ((uint64_t)1 << 21) : scan_fused_env != 0);
+    if (scan_fused) {
+        sortA_scan_fused_kernel<<<G, SORT_THREADS, 0, st>>>(histA, binstart, totals, bases, gstart + (size_t)G * P.nb, sort_bins, (uint32_t)(31 - __builtin_clz(sort_bins)), slices, arrivals);
+    } else {
+        sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
+        sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
+        sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
+    }
     static const int staged = [] { const char* e = getenv("BBGPU_SORT_STAGED"); return e ? atoi(e) : 3; }(); // tuning knob: bit 0 pass B, bit 1 pass A
     if ((staged & 2) && (P.n & 7u) == 0) {
         if (wide) sortA_scatter_staged_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,

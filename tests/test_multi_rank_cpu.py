@@ -220,6 +220,24 @@ def test_bench_launcher_reports_a_failed_rank():
     assert r.returncode == 7 and "rank 1 exited with 7" in r.stderr
 
 
+def test_bench_launcher_with_eight_ranks_and_one_that_fails():
+    """the driver's largest form, rehearsed on the CPU (a one-GPU box may hold at most 6 processes on its card, so the 8-rank case never runs on one): 8
+    rank processes form ONE gloo group of 8; when rank 5 exits non-zero the launcher ends the other seven and returns its code"""
+    import time
+    r, lines = _run_bench(["--gpus", "8", "--probe", "--backend", "gloo"])
+    assert r.returncode == 0, r.stderr
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["rccl_ranks"] == 8 and lines[0]["ranks"] == list(range(8))
+    pids = lines[0]["pids"]
+    assert len(set(pids)) == 8
+    t0 = time.time()
+    r, lines = _run_bench(["--gpus", "8", "--probe", "--backend", "gloo"], {"BBGPU_BENCH_PROBE_FAIL_RANK": "5"})
+    assert r.returncode == 7 and "rank 5 exited with 7" in r.stderr  # (rank 0 may have printed its probe line before rank 5 died: the exit code is what tells)
+    assert time.time() - t0 < 120  # the survivors were ended, not waited for until a collective times out
+    import subprocess
+    left = subprocess.run(["pgrep", "-f", "bench.py --gpus 8 --probe"], capture_output=True, text=True).stdout.split()
+    assert not left, left
+
+
 def test_bench_refuses_a_world_size_that_contradicts_the_flag():
     r, lines = _run_bench(["--gpus", "4", "--probe", "--backend", "gloo"], {"WORLD_SIZE": "2", "RANK": "0", "MASTER_PORT": "29999"})
     assert r.returncode == 2 and not lines and "WORLD_SIZE=2" in r.stderr
