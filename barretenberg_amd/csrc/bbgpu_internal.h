@@ -101,6 +101,7 @@ int msm_finish_batch(MsmSlot& S, host::Xyzz* results, MsmTiming* timing);
 int srs_build_table(const uint32_t* d_srs, size_t n, int c, int num_windows, int w_begin, int w_end, uint32_t** d_alloc_out, uint32_t** d_tab_out, hipStream_t st);
 int msm_finish(MsmSlot& S, host::Xyzz* result, MsmTiming* timing);
 int srs_upload(const uint64_t* host_table, size_t n, uint32_t** d_srs_out, hipStream_t st, size_t stride_bytes = 128);
+int srs_upload_into(const uint64_t* host_table, size_t n, uint32_t* d_raw, uint32_t* d_srs, hipStream_t st, size_t stride_bytes);
 int srs_generate(const uint64_t* x_mont256, size_t first, size_t n, uint32_t** d_srs_out, uint64_t* host_table_out, hipStream_t st);
 
 // capi.hip: the caller's host buffers cross the link through the library's OWN pinned buffers (see host_to_device)

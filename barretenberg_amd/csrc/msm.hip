@@ -510,65 +510,70 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
     }
 }
 
-// The three kernels above as ONE launch (round 5: a small MSM is a chain of dependent launches of ~5 us each, and these three are nothing but latency --
-// 6.7 + 4.8 + 5.1 us of a 253 us MSM of 2^16 points): one workgroup per group scans its [slices][bins] histogram matrix column by column (thread t owns
-// bin t % bins -- neighbouring lanes read neighbouring words -- and the slices of part t / bins), scans the bin totals in LDS, and the LAST group to
-// arrive (an agent-scope counter the digits kernel zeroed) lays down the window bases.  bins is a power of two <= SORT_THREADS.
-__global__ void __launch_bounds__(SORT_THREADS) sortA_scan_fused_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ binstart, uint32_t* __restrict__ totals,
-                                                                      uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t bins, uint32_t log_bins, uint32_t slices,
-                                                                      uint32_t* __restrict__ arrivals)
+// The three kernels above as ONE launch (round 5: a small MSM is a chain of dependent launches of ~5 us each, and the two that follow the column scan are
+// nothing but latency -- 4.8 + 5.1 us of a 253 us MSM of 2^16 points): the column scan as above (one wave per bin, 16 bins per workgroup), and the LAST
+// workgroup to arrive (an agent-scope counter the digits kernel zeroed) scans the bin totals of every group and lays down the window bases.  (A first
+// version that gave the whole matrix of a group to ONE workgroup was 18 us SLOWER than the three launches: 68 dependent load / store pairs per lane.)
+__global__ void __launch_bounds__(SORT_THREADS) sortA_scan_fused_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ bintot, uint32_t* __restrict__ binstart,
+                                                                      uint32_t* __restrict__ totals, uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t bins,
+                                                                      uint32_t slices, uint32_t* __restrict__ arrivals)
 {
     FRONT_PRIO();
     __shared__ uint32_t part[SORT_THREADS];
     __shared__ uint32_t last_flag;
-    const uint32_t wl = blockIdx.x, t = threadIdx.x, G = gridDim.x;
-    const uint32_t bin = t & (bins - 1), p = t >> log_bins, parts = SORT_THREADS >> log_bins;
-    uint32_t* H = histA + (size_t)wl * slices * bins + bin;
-    const uint32_t spp = (slices + parts - 1) / parts, s0 = min(slices, p * spp), s1 = min(slices, s0 + spp);
-    uint32_t sum = 0;
-    for (uint32_t sl = s0; sl < s1; sl++) sum += H[(size_t)sl * bins];
-    part[t] = sum; // [p][bin]
-    __syncthreads();
-    uint32_t before = 0, total = 0; // this bin: entries of the parts before mine, of all parts
-    for (uint32_t q = 0; q < parts; q++) {
-        const uint32_t v = part[(q << log_bins) + bin];
-        before += q < p ? v : 0u;
-        total += v;
+    const uint32_t wl = blockIdx.y, t = threadIdx.x, lane = t & 63, G = gridDim.y;
+    const uint32_t bin = blockIdx.x * (SORT_THREADS / 64) + (t >> 6);
+    if (bin < bins) { // whole waves
+        uint32_t* H = histA + (size_t)wl * slices * bins + bin;
+        const uint32_t spp = (slices + 63) / 64;
+        const uint32_t s0 = min(slices, lane * spp), s1 = min(slices, s0 + spp);
+        uint32_t sum = 0;
+        for (uint32_t sl = s0; sl < s1; sl++) sum += H[(size_t)sl * bins];
+        uint32_t incl = sum; // inclusive scan over the 64 lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        uint32_t run = incl - sum;
+        for (uint32_t sl = s0; sl < s1; sl++) {
+            const uint32_t cnt = H[(size_t)sl * bins];
+            H[(size_t)sl * bins] = run;
+            run += cnt;
+        }
+        if (lane == 63) bintot[(size_t)wl * bins + bin] = incl;
     }
-    uint32_t run = before;
-    for (uint32_t sl = s0; sl < s1; sl++) {
-        const uint32_t cnt = H[(size_t)sl * bins];
-        H[(size_t)sl * bins] = run;
-        run += cnt;
-    }
+    __threadfence(); // this workgroup's bin totals are visible device-wide before it counts as arrived
     __syncthreads();
-    // exclusive scan of the bin totals (threads [0, bins) hold them)
-    const uint32_t mine = t < bins ? total : 0u;
-    part[t] = mine;
+    if (t == 0) last_flag = (atomicAdd(arrivals, 1u) == gridDim.x * gridDim.y - 1) ? 1u : 0u;
     __syncthreads();
-    for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
-        const uint32_t v = t >= off ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    if (t < bins) binstart[(size_t)wl * bins + t] = part[t] - mine;
-    if (t == SORT_THREADS - 1) {
-        totals[wl] = part[SORT_THREADS - 1];
-        __threadfence(); // the group's total is visible device-wide before the group counts as arrived
-        last_flag = (atomicAdd(arrivals, 1u) == G - 1) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!last_flag || t != 0) return;
-    __threadfence(); // acquire: the other groups' totals
-    uint32_t acc = 0;
+    if (!last_flag) return;
+    __threadfence(); // acquire: every other workgroup's bin totals
+    uint32_t acc = 0; // running window base (the same in every thread)
     for (uint32_t w = 0; w < G; w++) {
-        bases[w] = acc;
-        acc += __atomic_load_n(&totals[w], __ATOMIC_RELAXED);
+        const uint32_t mine = t < bins ? __atomic_load_n(&bintot[(size_t)w * bins + t], __ATOMIC_RELAXED) : 0u;
+        part[t] = mine;
+        __syncthreads();
+        for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
+            const uint32_t v = t >= off ? part[t - off] : 0u;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        if (t < bins) binstart[(size_t)w * bins + t] = part[t] - mine;
+        const uint32_t total = part[SORT_THREADS - 1];
+        if (t == 0) {
+            totals[w] = total;
+            bases[w] = acc;
+        }
+        acc += total;
+        __syncthreads(); // part[] is rewritten by the next group
     }
-    bases[G] = acc;
-    gstart_end[0] = acc;
-    gstart_end[1] = 0xffffffffu; // sentinel, as in sort_bases_kernel
+    if (t == 0) {
+        bases[G] = acc;
+        gstart_end[0] = acc;
+        gstart_end[1] = 0xffffffffu; // sentinel, as in sort_bases_kernel
+    }
 }
 
 template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, const uint32_t* __restrict__ cursorsA,
@@ -2002,10 +2007,11 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
     // the scans between the two halves of pass A: one launch up to 2^21 entries (a chain of dependent launches is what a small MSM is made of), three wider ones above
     static const int scan_fused_env = [] { const char* e = getenv("BBGPU_SORT_SCAN_FUSED"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force
-    const bool scan_fused = (sort_bins & (sort_bins - 1)) == 0 && sort_bins <= (uint32_t)SORT_THREADS && G <= 64 &&
+    const bool scan_fused = sort_bins <= (uint32_t)SORT_THREADS && G <= 64 &&
                             (scan_fused_env < 0 ? (uint64_t)n * nw < ((uint64_t)1 << 21) : scan_fused_env != 0);
     if (scan_fused) {
-        sortA_scan_fused_kernel<<<G, SORT_THREADS, 0, st>>>(histA, binstart, totals, bases, gstart + (size_t)G * P.nb, sort_bins, (uint32_t)(31 - __builtin_clz(sort_bins)), slices, arrivals);
+        sortA_scan_fused_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, binstart, totals, bases, gstart + (size_t)G * P.nb, sort_bins, slices,
+                                                                                                                        arrivals);
     } else {
         sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
         sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
@@ -2241,6 +2247,16 @@ int srs_upload(const uint64_t* host_table, size_t n, uint32_t** d_srs_out, hipSt
     HIPCHK(launch_check());
     HIPCHK(hipStreamSynchronize(st));
     *d_srs_out = srs.release<uint32_t>();
+    return BBGPU_OK;
+}
+
+// the same into buffers the caller owns (d_raw: n * stride_bytes, d_srs: n * 64), everything enqueued on `st`, nothing waited for: the caller runs its kernels
+// behind it on the same stream (small tables that are used once: no allocation, no free, no synchronisation on their path)
+int srs_upload_into(const uint64_t* host_table, size_t n, uint32_t* d_raw, uint32_t* d_srs, hipStream_t st, size_t stride_bytes)
+{
+    if (int rc = host_to_device(d_raw, host_table, n * stride_bytes, st)) return rc;
+    srs_convert_kernel<<<(uint32_t)((n + 127) / 128), 128, 0, st>>>(d_raw, d_srs, (uint32_t)n, (uint32_t)(stride_bytes / 4));
+    HIPCHK(launch_check());
     return BBGPU_OK;
 }
 
