@@ -307,10 +307,9 @@ template <class DT> __device__ __forceinline__ void load_digits8(const DT* __res
     }
 }
 template <class DT> __global__ void __launch_bounds__(MSM_THREADS) msm_digits_kernel(ScalarSets sets, DT* __restrict__ digits_all, unsigned long long* __restrict__ signs_all,
-                                                               uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we, uint32_t* __restrict__ zero_word)
+                                                               uint32_t n, WinLayout LO, uint32_t num_windows, uint32_t wb, uint32_t we)
 {
     FRONT_PRIO();
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0; // the arrival counter of sortA_scan_fused_kernel, two launches down the stream
     // only windows [wb, we) are stored (a rank of a window-sharded MSM needs its share only); the carry chain still starts at window 0
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -510,71 +509,10 @@ __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t*
     }
 }
 
-// The three kernels above as ONE launch (round 5: a small MSM is a chain of dependent launches of ~5 us each, and the two that follow the column scan are
-// nothing but latency -- 4.8 + 5.1 us of a 253 us MSM of 2^16 points): the column scan as above (one wave per bin, 16 bins per workgroup), and the LAST
-// workgroup to arrive (an agent-scope counter the digits kernel zeroed) scans the bin totals of every group and lays down the window bases.  (A first
-// version that gave the whole matrix of a group to ONE workgroup was 18 us SLOWER than the three launches: 68 dependent load / store pairs per lane.)
-__global__ void __launch_bounds__(SORT_THREADS) sortA_scan_fused_kernel(uint32_t* __restrict__ histA, uint32_t* __restrict__ bintot, uint32_t* __restrict__ binstart,
-                                                                      uint32_t* __restrict__ totals, uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t bins,
-                                                                      uint32_t slices, uint32_t* __restrict__ arrivals)
-{
-    FRONT_PRIO();
-    __shared__ uint32_t part[SORT_THREADS];
-    __shared__ uint32_t last_flag;
-    const uint32_t wl = blockIdx.y, t = threadIdx.x, lane = t & 63, G = gridDim.y;
-    const uint32_t bin = blockIdx.x * (SORT_THREADS / 64) + (t >> 6);
-    if (bin < bins) { // whole waves
-        uint32_t* H = histA + (size_t)wl * slices * bins + bin;
-        const uint32_t spp = (slices + 63) / 64;
-        const uint32_t s0 = min(slices, lane * spp), s1 = min(slices, s0 + spp);
-        uint32_t sum = 0;
-        for (uint32_t sl = s0; sl < s1; sl++) sum += H[(size_t)sl * bins];
-        uint32_t incl = sum; // inclusive scan over the 64 lanes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off);
-            if ((int)lane >= off) incl += v;
-        }
-        uint32_t run = incl - sum;
-        for (uint32_t sl = s0; sl < s1; sl++) {
-            const uint32_t cnt = H[(size_t)sl * bins];
-            H[(size_t)sl * bins] = run;
-            run += cnt;
-        }
-        if (lane == 63) bintot[(size_t)wl * bins + bin] = incl;
-    }
-    __threadfence(); // this workgroup's bin totals are visible device-wide before it counts as arrived
-    __syncthreads();
-    if (t == 0) last_flag = (atomicAdd(arrivals, 1u) == gridDim.x * gridDim.y - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!last_flag) return;
-    __threadfence(); // acquire: every other workgroup's bin totals
-    uint32_t acc = 0; // running window base (the same in every thread)
-    for (uint32_t w = 0; w < G; w++) {
-        const uint32_t mine = t < bins ? __atomic_load_n(&bintot[(size_t)w * bins + t], __ATOMIC_RELAXED) : 0u;
-        part[t] = mine;
-        __syncthreads();
-        for (uint32_t off = 1; off < SORT_THREADS; off <<= 1) {
-            const uint32_t v = t >= off ? part[t - off] : 0u;
-            __syncthreads();
-            part[t] += v;
-            __syncthreads();
-        }
-        if (t < bins) binstart[(size_t)w * bins + t] = part[t] - mine;
-        const uint32_t total = part[SORT_THREADS - 1];
-        if (t == 0) {
-            totals[w] = total;
-            bases[w] = acc;
-        }
-        acc += total;
-        __syncthreads(); // part[] is rewritten by the next group
-    }
-    if (t == 0) {
-        bases[G] = acc;
-        gstart_end[0] = acc;
-        gstart_end[1] = 0xffffffffu; // sentinel, as in sort_bases_kernel
-    }
-}
+// (Round 5 tried these three kernels as ONE launch -- the two after the column scan are nothing but launch latency, 4.8 + 5.1 us of a 253 us MSM of 2^16
+// points -- twice: the whole matrix of a group on one workgroup, and the column scan as above with the LAST workgroup to arrive scanning the bin totals and
+// laying down the bases.  Both were SLOWER than the three launches in one-box A/Bs, 0.277 against 0.257-0.261 ms per 2^16-point MSM (profiles/r05_scan_fused_ab.txt):
+// the agent-scope release / acquire around the arrival counter writes back and invalidates the XCD's L2, in every workgroup, where a kernel boundary does it once.)
 
 template <class DT> __global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_vgpr(32))) sortA_scatter_kernel(const DT* __restrict__ digits, const unsigned long long* __restrict__ signs, const uint32_t* __restrict__ cursorsA,
                                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ bases,
@@ -1604,8 +1542,7 @@ __global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_final_quad_kernel(const 
 
 int msm_choose_c(size_t n)
 {
-    static const int forced = [] { const char* e = getenv("BBGPU_PLAIN_C"); return e ? std::min((int)MSM_MAX_C, std::max(4, atoi(e))) : 0; }(); // tuning knob: window size of MSMs WITHOUT window tables
-    if (forced) return forced;
+    // (round 5 swept fixed window sizes 5 .. 10 for the table-less small MSMs, 32 .. 1000 points, against this rule: nothing better, profiles/r05_small_sizes.txt)
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
     int c = lg - 4;
@@ -1998,25 +1935,15 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     ScalarSets sets{};
     for (int j = 0; j < jobs; j++) sets.p[j] = (const uint32_t*)d_scalars_v[j];
     const bool wide = c > 16; // 17-bit windows: signed digits up to +-2^16
-    uint32_t* const arrivals = bases + nw + 16; // inside the 512 spare bytes of the `totals` block (carve): zeroed by the digits kernel, counted up by the fused scan
-    if (wide) msm_digits_kernel<uint16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (uint16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we, arrivals);
-    else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we, arrivals);
+    if (wide) msm_digits_kernel<uint16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (uint16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
+    else msm_digits_kernel<int16_t><<<dim3((P.n + MSM_THREADS - 1) / MSM_THREADS, jobs), MSM_THREADS, 0, st>>>(sets, (int16_t*)digits, signs, P.n, make_layout(c, table), P.W, (uint32_t)wb, (uint32_t)we);
     if (tm) HIPCHK(hipEventRecord(ev[1], st));
     // K1-K3
     if (wide) sortA_hist_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
     else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
-    // the scans between the two halves of pass A: one launch up to 2^21 entries (a chain of dependent launches is what a small MSM is made of), three wider ones above
-    static const int scan_fused_env = [] { const char* e = getenv("BBGPU_SORT_SCAN_FUSED"); return e ? atoi(e) : -1; }(); // tuning knob: 0 / 1 force
-    const bool scan_fused = sort_bins <= (uint32_t)SORT_THREADS && G <= 64 &&
-                            (scan_fused_env < 0 ? (uint64_t)n * nw < ((uint64_t)1 << 21) : scan_fused_env != 0);
-    if (scan_fused) {
-        sortA_scan_fused_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, binstart, totals, bases, gstart + (size_t)G * P.nb, sort_bins, slices,
-                                                                                                                        arrivals);
-    } else {
-        sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
-        sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
-        sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
-    }
+    sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
+    sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
+    sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
     static const int staged = [] { const char* e = getenv("BBGPU_SORT_STAGED"); return e ? atoi(e) : 3; }(); // tuning knob: bit 0 pass B, bit 1 pass A
     if ((staged & 2) && (P.n & 7u) == 0) {
         if (wide) sortA_scatter_staged_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,

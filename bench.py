@@ -616,6 +616,8 @@ def main():
     msm_ms = dt / args.steps * 1e3
     # latency of one isolated MSM (no pipelining): median of 10 after 3
     msm_latency_ms, msm_latency_min = median_ms(lambda: finish(issue()), 10, 3)
+    # what this rank holds for ITS share, before the full-size comparison runs below allocate theirs (N > 1: the workspace must be sized by the share)
+    resident_after_timed = G.memory_stats()
     barrier()
 
     # window-sharded result == the same MSM done by one rank alone (outside the timed region)
@@ -858,7 +860,8 @@ def main():
                                           "srs_setup_ms": srs_setup_ms, "srs_setup_what": "bbgpu_srs_generate: points + window tables" + (" + host copy of the point table" if table is not None else ""),
                                           "srs_table_bytes": int(min(we_tab - wb_tab, W) * (pt1 - pt0) * 64) if not args.no_window_tables and W * n <= (1 << 24) else 0, "srs_points_bytes": (pt1 - pt0) * 64,
                                           "ntt_table_bytes": int(4 * n * 32) if n <= (1 << 22) else None,
-                                          "resident_now": G.memory_stats(),  # bbgpu_memory_stats at the end of the run: SRS points / window tables, NTT tables (all domain sizes used, under their byte budget), workspaces, pinned host memory
+                                          "resident_after_timed_region": resident_after_timed,  # the headline leg alone: SRS share + its workspaces (rank 0)
+                                         "resident_now": G.memory_stats(),  # bbgpu_memory_stats at the end of the run: SRS points / window tables, NTT tables (all domain sizes used, under their byte budget), workspaces, pinned host memory
                                           },
                        "parallelism": ("%d digit windows x n points sharded %s over %d ranks, one all-gather of 96 B partial sums" % (W, "by point range (n / N points and scalars each, all windows)" if by_points else "by bucket range (all windows and points, 1 / N of the buckets each)" if by_buckets else "by table row (W n / N rows each)" if by_rows else "by window", world)) if world > 1 else "single GPU, %d digit windows of %d bits" % (W, -(-254 // W)),
                        "srs": "resident, with pre-shifted window tables" if not args.no_window_tables else "resident base points only"},

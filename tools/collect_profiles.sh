@@ -3,11 +3,14 @@
 #   tools/collect_profiles.sh <tag>        (tag = r02 ...; outputs land in gpurun_out/prof_<tag>/, summaries are copied by hand)
 # Counter passes carry --pmc only (no tracing domains), one counter group per pass, as MI355X_MICROARCH.md prescribes.
 set -o pipefail
+#   tools/collect_profiles.sh <tag> 1 | 2   the traces and counter passes (1) or the tool runs behind them (2) alone: one gpurun call holds 20 minutes
 TAG=${1:-r05}
+PART=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [ "$PART" != 2 ]; then
 BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-plonk --no-boundary"
 BENCH_PMC="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-boundary"
 echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
@@ -37,6 +40,9 @@ $ROOT/tools/ubench/ubench_traffic > $OUT/ubench_traffic.txt 2>&1
 # keep the merged scratch small: the raw traces of the counter passes are not needed once summarised
 rm -rf $OUT/fetch $OUT/write $OUT/cal_fetch $OUT/cal_write $OUT/sq $OUT/ntt22_fetch $OUT/ntt22_write
 find $OUT/trace $OUT/plonk -name "*kernel_trace.csv" -size +20M -delete
+fi
+cd $ROOT
+[ "$PART" = 1 ] && exit 0
 echo "== shard prediction"
 python tools/shard_sim.py $OUT/${TAG}_shard_prediction.json > $OUT/shard_sim.txt 2>&1; tail -6 $OUT/shard_sim.txt
 python tools/ntt_sizes.py > $OUT/ntt_sizes.txt 2>&1
@@ -54,6 +60,8 @@ for g in 1048576 2097152; do python tools/plonk_bench.py --gates $g --reps 5 --n
 python tools/skewed_stages.py > $OUT/skewed_stages.txt 2>&1
 python tools/boundary_ab.py > $OUT/boundary_ab.txt 2>&1
 BBGPU_HOST_MSM_SPLIT=1 python tools/boundary_ab.py >> $OUT/boundary_ab.txt 2>&1
+python tools/validate_ab.py >> $OUT/boundary_ab.txt 2>&1
+python tools/ntt_ramp.py 500 > $OUT/ntt_ramp.txt 2>&1
 python tools/acc_ab.py > $OUT/acc_ab.txt 2>&1
 $ROOT/tools/ubench/ubench_pcie > $OUT/pcie.txt 2>&1
 export OMP_NUM_THREADS=16
