@@ -334,6 +334,8 @@ def device_ntt_leg(G, dev, d_vec, n, kinds, steps, warmup, barrier):
     torch.cuda.synchronize()
     out = {}
     for kind in kinds:
+        for _ in range(2):  # the first transform of a domain size / kind builds its tables: not part of the estimate below
+            G.ntt_device(d_vec.data_ptr(), n, kind, stream=stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(tstream)
         for _ in range(8):
@@ -352,7 +354,7 @@ def device_ntt_leg(G, dev, d_vec, n, kinds, steps, warmup, barrier):
         e1.record(tstream)
         barrier()
         wall = (time.perf_counter() - t0) / steps
-        out[kind] = {"ms_per_step": wall * 1e3, "elements_per_s": n / wall, "device_ms": e0.elapsed_time(e1) / steps, "untimed_ramp_transforms": ramp + 8, "warmup": warmup}
+        out[kind] = {"ms_per_step": wall * 1e3, "elements_per_s": n / wall, "device_ms": e0.elapsed_time(e1) / steps, "untimed_ramp_transforms": ramp + 10, "warmup": warmup}
     return out
 
 

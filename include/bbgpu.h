@@ -136,9 +136,11 @@ int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
  * against the resident copy; if a single row differs the copy is dropped (a table registered on first sight is evicted, an explicitly registered one
  * stops serving host-pointer calls; its handle stays valid) and the call runs once more on a fresh upload: identical inputs -> identical outputs on
  * the very next call, whatever part of the table was rewritten.  srs_handle -1 sets the default for tables registered from now on (on first sight
- * or explicitly); the environment variable BBGPU_SRS_VALIDATE=full does the same at start-up.  Cost (tools/boundary_ab.py, profiles/r05_boundary_ab.txt)
- * is printed there for 2^16 and 2^20 points; the default stays the 16-row sample because the full check of a 2^20-point table reads 64 MiB of host
- * memory per call. */
+ * or explicitly); the environment variable BBGPU_SRS_VALIDATE=full does the same at start-up.  Cost on MI355X + EPYC 9575F (tools/validate_ab.py,
+ * profiles/r05_boundary_ab.txt, one box, alternating): bbgpu_msm_g1 at 2^16 points 0.352 -> 0.352 ms (+0.1 %: the check hides behind the kernels), at 2^20
+ * points 1.71 -> 2.07 ms (+21 %: 64 MiB of host memory hashed per call, longer than the kernels it runs beside); a batch of three 2^20-point jobs over one
+ * table 4.68 -> 4.73 ms (+0.9 %: one check per distinct range).  Above 5 % at the headline size, so the DEFAULT STAYS THE 16-ROW SAMPLE and the residual
+ * window described above stays with it; a caller that rewrites live tables in place sets the flag. */
 int bbgpu_srs_set_validate(int srs_handle, int full);
 /* Registration also builds, on the device, the pre-shifted window tables 2^(c w) * P_i (the reference's
  * generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129): W x n x 64 bytes (1 GiB at n = 2^20), so that

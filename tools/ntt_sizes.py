@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""device-resident NTT timing across sizes (HIP events on the launch stream)"""
+"""device-resident NTT timing across sizes (HIP events on the launch stream), steady state: ~80 ms of untimed transforms before every timed batch of 20"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,6 +13,12 @@ for lg in (12, 14, 16, 18, 20, 21, 22, 23, 24, 26):
     for kind in ("fft", "coset_fft"):
         for _ in range(3): G.ntt_device(d.data_ptr(), n, kind, stream=s.cuda_stream)
         torch.cuda.synchronize()
+        # out of the post-idle ramp first (tools/ntt_ramp.py: the first ~30 ms of back-to-back transforms run up to 15 % slow): ~80 ms of untimed transforms
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(s)
+        for _ in range(4): G.ntt_device(d.data_ptr(), n, kind, stream=s.cuda_stream)
+        r1.record(s); torch.cuda.synchronize()
+        for _ in range(int(80.0 / max(1e-3, r0.elapsed_time(r1) / 4))): G.ntt_device(d.data_ptr(), n, kind, stream=s.cuda_stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
         for _ in range(20): G.ntt_device(d.data_ptr(), n, kind, stream=s.cuda_stream)
