@@ -51,7 +51,7 @@ struct MsmWorkspace {
     uint8_t* base = nullptr;
     size_t cap = 0;
     void* h_out = nullptr; // pinned
-    static size_t bytes_needed(size_t n, int c, int nw);
+    static size_t bytes_needed(size_t n, int c, int nw, int ng = 0); // nw (job, window) pairs, ng bucket sets (0: one per pair = no window tables)
     int ensure(size_t bytes);
     void release();
 };

@@ -760,7 +760,7 @@ int issue_ticket(int t, const SrsEntry& e, size_t off, const uint64_t* const* d_
         size_t largest[2] = { 0, 0 };
         for (int k = 0; k < np; k++) largest[(H && (k & 1)) ? 1 : 0] = std::max(largest[(H && (k & 1)) ? 1 : 0], pc[k].len);
         for (int side = 0; side < 2 && rc == BBGPU_OK; side++)
-            if (largest[side]) rc = (side ? *H : S).ws.ensure(MsmWorkspace::bytes_needed(largest[side], e.tab_c, (we - wb) * jobs));
+            if (largest[side]) rc = (side ? *H : S).ws.ensure(MsmWorkspace::bytes_needed(largest[side], e.tab_c, (we - wb) * jobs, jobs)); // pieces run against window tables: one bucket set per job
         if (rc != BBGPU_OK) return rc;
     }
     for (int k = 0; k < np && rc == BBGPU_OK; k++) {

@@ -1684,7 +1684,10 @@ struct MsmCarve {
     size_t digits, signs, histA, histB, binstart, bintot, tmp_entries, gstart, totals, heavy, sorted, partials, buckets, arena, segs, texp, end;
     size_t chunks_cap, histB_bytes;
 };
-static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
+// nw: (job, window) pairs = what the entry lists scale with; ng: BUCKET SETS = what the bucket-side arrays scale with -- nw without window tables (one set per
+// window), the number of jobs with them (every window feeds the job's one shared set).  Round 5: the bucket-side arrays were sized by nw in both modes, 15 times
+// what a 2^20-point MSM against window tables touches (0.85 GB per slot instead of 0.5).
+static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw, size_t ng)
 {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     MsmCarve L;
@@ -1699,22 +1702,22 @@ static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw)
     L.binstart = p;    p += al(nw * 1024 * 4 + 256);
     L.bintot = p;      p += al(nw * 1024 * 4 + 256);
     L.tmp_entries = p; p += al(nw * n * 4);                      // pass-A output
-    L.gstart = p;      p += al((nw * P.nb + 2) * 4);             // + M at [total_buckets] + a sentinel behind it
+    L.gstart = p;      p += al((ng * P.nb + 2) * 4);             // + M at [total_buckets] + a sentinel behind it
     L.totals = p;      p += al(nw * 8 + 512);                    // totals, bases (nw + 1)
-    L.heavy = p;       p += al((nw * P.nb + HEAVY_IDS) * 4 + 256 + (size_t)HEAVY_WGS * RAW_WORDS * 4); // heavy-bucket queue: count, arrival counters, ids, slice sums
+    L.heavy = p;       p += al((ng * P.nb + HEAVY_IDS) * 4 + 256 + (size_t)HEAVY_WGS * RAW_WORDS * 4); // heavy-bucket queue: count, arrival counters, ids, slice sums
     L.sorted = p;      p += al(nw * n * 4);
     L.chunks_cap = (n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1;     // upper bound for any chunk length >= MIN_CHUNK
-    L.partials = p;    p += al((nw * P.nb + L.chunks_cap) * RAW_WORDS * 4);
-    L.buckets = p;     p += al(nw * P.nb * 128);
-    L.arena = p;       p += al(arena_points(P, (uint32_t)nw) * 128); // row sums + column sums
-    L.segs = p;        p += al(seg_points(P, (uint32_t)nw) * 128);   // segment sums of the two-step row / column sums (large bucket sets)
-    L.texp = p;        p += al(nw * 64 * 128);                   // exported T points
+    L.partials = p;    p += al((ng * P.nb + L.chunks_cap) * RAW_WORDS * 4);
+    L.buckets = p;     p += al(ng * P.nb * 128);
+    L.arena = p;       p += al(arena_points(P, (uint32_t)ng) * 128); // row sums + column sums
+    L.segs = p;        p += al(seg_points(P, (uint32_t)ng) * 128);   // segment sums of the two-step row / column sums (large bucket sets)
+    L.texp = p;        p += al(ng * 64 * 128);                   // exported T points
     L.end = p;
     return L;
 }
-size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw)
+size_t MsmWorkspace::bytes_needed(size_t n, int c, int nw, int ng)
 {
-    return carve(make_plan(n, c), n, (size_t)nw).end;
+    return carve(make_plan(n, c), n, (size_t)nw, (size_t)(ng > 0 ? ng : nw)).end;
 }
 
 int MsmWorkspace::ensure(size_t bytes)
@@ -1875,12 +1878,12 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     }
     // (capi.hip issue_ticket() sizes the workspace for the LARGEST piece of a multi-piece MSM before piece 0 is issued -- a slice that starts mid-segment has
     // its largest piece in the middle -- so that this never frees a workspace under a piece still queued on the stream)
-    int rc = ws.ensure(MsmWorkspace::bytes_needed(n, c, (int)nw));
+    int rc = ws.ensure(MsmWorkspace::bytes_needed(n, c, (int)nw, (int)G));
     if (rc) return rc;
     if (!ws.h_out) HIPCHK(hipHostMalloc((void**)&ws.h_out, (size_t)MSM_HOUT_GROUPS * 64 * 128));
     if (!S.done) HIPCHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
 
-    const MsmCarve LY = carve(P, n, nw);
+    const MsmCarve LY = carve(P, n, nw, G);
     if (LY.end > ws.cap) { // cannot happen while bytes_needed and this carve share one table; checked before anything is launched
         set_error("internal: MSM workspace of %zu bytes, layout needs %zu (n=%zu c=%d nw=%u)", ws.cap, LY.end, n, c, nw);
         return BBGPU_ERR_STATE;
@@ -1904,7 +1907,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     uint32_t* texp = (uint32_t*)(p + LY.texp);
     // launch-shape checks against the carve (the kernels index these arrays from these quantities)
     if ((uint64_t)G * slices * sort_bins > (uint64_t)nw * P.slices * 1024 || sort_bins > 1024 ||
-        (size_t)G * ((size_t)(1u << P.hbits) + (size_t)(1u << P.lbits)) + 64 > arena_points(P, nw)) {
+        (size_t)G * ((size_t)(1u << P.hbits) + (size_t)(1u << P.lbits)) + 64 > arena_points(P, G)) {
         set_error("internal: MSM launch shape exceeds the workspace layout");
         return BBGPU_ERR_STATE;
     }
@@ -2020,7 +2023,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     } else
     msm_merge_kernel<<<(uint32_t)((((uint64_t)merge_buckets << logG) + MSM_THREADS - 1) / MSM_THREADS), MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy,
                                                                                                                      blo, blo + merge_buckets, ch, merge_light, logG);
-    msm_merge_heavy_kernel<<<HEAVY_WGS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch, heavy + (((size_t)nw * P.nb + HEAVY_IDS + 63) & ~(size_t)63));
+    msm_merge_heavy_kernel<<<HEAVY_WGS, MSM_THREADS, 0, st>>>(gstart, partials, buckets, heavy, ch, heavy + (((size_t)G * P.nb + HEAVY_IDS + 63) & ~(size_t)63));
     if (tm) HIPCHK(hipEventRecord(ev[4], st));
 
     // K5: bucket b = hi * 2^l + lo carries weight b + 1:
