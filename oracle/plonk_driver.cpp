@@ -553,6 +553,7 @@ int faults(size_t num_gates, const char* kind, size_t first, size_t step)
         // allocates -- so the three srs_* figures are not comparable between runs; they are bounded by BBGPU_SRS_CACHE_BYTES, and a leaked table would
         // still show in the last line (live allocations after shutdown).  Everything else must be what two healthy proofs leave behind.
         m1.srs_points_bytes = m0.srs_points_bytes; m1.srs_table_bytes = m0.srs_table_bytes; m1.srs_auto_bytes = m0.srs_auto_bytes;
+        if (fi.absorbed) m1.msm_workspace_bytes = m0.msm_workspace_bytes; // an SRS that lost its window tables to the failure: its MSMs take one bucket set per window (a larger workspace)
         printf("fault %s %llu fired %llu absorbed %llu fallbacks_failed_proof %llu fallbacks_next_proof %llu proof_same %d next_same %d verified %d pending %llu mem_same %d\n", kind,
                (unsigned long long)k, (unsigned long long)fi.fired, (unsigned long long)fi.absorbed, f1 - f0, f2 - f1, !memcmp(p1.b, good.b, sizeof good.b),
                !memcmp(p2.b, good.b, sizeof good.b), (int)(p1.ok && p2.ok), (unsigned long long)fj.slots_pending, !memcmp(&m0, &m1, sizeof m0));
