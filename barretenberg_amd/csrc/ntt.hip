@@ -92,6 +92,21 @@ __device__ __forceinline__ FeT<Fr> load_tw(const uint32_t* table, uint32_t idx)
     return r;
 }
 
+// the same entry out of LDS (north star: "LDS-staged twiddles"; fused kernel, 2048-element tiles): 12-word entries, three 16-byte reads
+__device__ __forceinline__ FeT<Fr> load_tw_lds(const uint32_t* lds_table, uint32_t idx)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(lds_table + TW_WORDS * idx);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    FeT<Fr> r;
+    r.d[0] = a.x; r.d[1] = a.y; r.d[2] = a.z; r.d[3] = a.w;
+    r.d[4] = b.x; r.d[5] = b.y; r.d[6] = b.z; r.d[7] = b.w;
+    r.d[8] = c.x;
+    return r;
+}
+// Entries of the sub-transform's twiddle table the middle stage pairs up to s = 6 read: indices j << (log_s - 1 - s), j << (log_s - 2 - s), (j + m) << (log_s - 2 - s),
+// j < m = 2^s -- all multiples of 2^(log_s - 8), at most 127 of them: 128 entries = 6 KiB staged beside a 72 KiB tile (two workgroups per CU: 159,744 of 163,840 bytes).
+constexpr uint32_t NTT_TW_LDS_ENTRIES = 128;
+
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits)
 {
     return __brev(x) >> (32 - bits);
@@ -128,6 +143,7 @@ struct NttPassArgs {
     uint32_t xcd_remap;       // 1: contiguous tile range per XCD (see ntt_pass_kernel)
     uint32_t batch;           // transforms in this launch (blockIdx.y): transform j works on in + j * in_bstride -> out + j * out_bstride
     size_t in_bstride, out_bstride; // in words
+    uint32_t tw_lds;          // fused kernel, 512-thread instance: stage the middle pairs' twiddles in LDS (the launch reserved NTT_TW_LDS_ENTRIES entries behind the tile)
     uint32_t nat_bstep;       // natural output index of batch item j starts at j * nat_bstep (three-pass transforms: rows of one big transform; else 0)
 };
 
@@ -409,6 +425,16 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
     const uint32_t b0 = bid * cols;
     const uint32_t tid = threadIdx.x;
     using In = Fe<Fr, 1, 6>; // what unpack() / the pre-scale product really hold
+#ifndef BBGPU_NTT_TW_GLOBAL // (-DBBGPU_NTT_TW_GLOBAL: every twiddle from the L1 / L2-resident table, the round-2 .. 4 form: A/B)
+    // LDS-staged twiddles of the middle stage pairs (A.tw_lds: the host asks for it where the launch reserved the room): entry e = table entry e << (log_s - 8),
+    // copied by the first 384 threads while everybody's first loads are in flight; the barrier behind phase A publishes it
+    uint32_t* const lds_tw = lds + NL * E;
+    const uint32_t tw_shift = A.log_s - 8;
+    if (A.tw_lds && tid < NTT_TW_LDS_ENTRIES * 3) {
+        const uint32_t e = tid / 3, part = tid - 3 * e;
+        reinterpret_cast<uint4*>(lds_tw + TW_WORDS * e)[part] = reinterpret_cast<const uint4*>(A.tw_sub + TW_WORDS * ((size_t)e << tw_shift))[part];
+    }
+#endif
 
     // ---- A: load (+ coset pre-scale) + stage pair (0, 1) ------------------------------------------------------------------
     for (uint32_t gq = tid; gq < ngr; gq += THREADS) {
@@ -477,9 +503,22 @@ template <int FLAGS, int THREADS> __global__ void __launch_bounds__(THREADS) NTT
                 x2.d[l] = lds[l * E + e2];
                 x3.d[l] = lds[l * E + e3];
             }
+#ifndef BBGPU_NTT_TW_GLOBAL
+            FeT<Fr> w1, w2a, w2b;
+            if (A.tw_lds && s <= 6) { // (j << (log_s - 1 - s)) >> (log_s - 8) = j << (7 - s), ...
+                w1 = load_tw_lds(lds_tw, j << (7 - s));
+                w2a = load_tw_lds(lds_tw, j << (6 - s));
+                w2b = load_tw_lds(lds_tw, (j + m) << (6 - s));
+            } else {
+                w1 = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
+                w2a = load_tw(A.tw_sub, j << (A.log_s - 2 - s));
+                w2b = load_tw(A.tw_sub, (j + m) << (A.log_s - 2 - s));
+            }
+#else
             const FeT<Fr> w1 = load_tw(A.tw_sub, j << (A.log_s - 1 - s));
             const FeT<Fr> w2a = load_tw(A.tw_sub, j << (A.log_s - 2 - s));
             const FeT<Fr> w2b = load_tw(A.tw_sub, (j + m) << (A.log_s - 2 - s));
+#endif
             const Radix4Out o = radix4_lazy(x0, x1, x2, x3, w1, w2a, w2b);
             const FrL y3 = weak(o.y3); // 5 U would reach 7 U in the x2 role of the next pair
 #pragma unroll
@@ -841,7 +880,7 @@ template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
-        (void)hipFuncSetAttribute((const void*)ntt_pass_fused_kernel<FLAGS, NTT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
+        (void)hipFuncSetAttribute((const void*)ntt_pass_fused_kernel<FLAGS, NTT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4 + NTT_TW_LDS_ENTRIES * TW_WORDS * 4);
         (void)hipFuncSetAttribute((const void*)ntt_pass_fused_kernel<FLAGS, 2 * NTT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NTT_LDS_ELEMS * NL * 4);
         (void)hipFuncSetAttribute((const void*)ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_ELEMS * NL * 4);
         attr_set = true;
@@ -857,8 +896,16 @@ template <int FLAGS> hipError_t launch_pass(const NttPassArgs& A, hipStream_t st
             static const size_t pad = [] { const char* e = getenv("BBGPU_NTT_LDS_PAD"); return e ? std::min<size_t>((size_t)2 * NTT_THREADS * NL * 4, (size_t)strtoull(e, nullptr, 0)) : (size_t)0; }(); // tuning experiment: extra LDS bytes per half-tile workgroup (36864 = two workgroups per CU)
             ntt_pass_fused_kernel<FLAGS, NTT_THREADS / 2><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS / 2, (size_t)2 * NTT_THREADS * NL * 4 + pad, st>>>(B);
         }
-        else
+        else {
+#ifndef BBGPU_NTT_TW_GLOBAL
+            // Round 5, one box, steady state (profiles/r05_ntt_twlds_ab.txt): 2^22 fft 0.416 -> 0.396 ms (-3.5 ... 5.7 % by kind: its 1024-entry tables, 48 KiB, do not fit the 32 KiB L1),
+            // 2^20 level (512 entries do); the 256-thread instance (sizes below 2^20) has no room for the table beside four 36 KiB tiles per CU and keeps the global loads
+            B.tw_lds = A.log_s >= 8 ? 1u : 0u; // 128 staged entries cover the pairs up to s = 6 of sub-transforms of 256 points and more
+            ntt_pass_fused_kernel<FLAGS, NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, (size_t)4 * NTT_THREADS * NL * 4 + (B.tw_lds ? NTT_TW_LDS_ENTRIES * TW_WORDS * 4 : 0), st>>>(B);
+#else
             ntt_pass_fused_kernel<FLAGS, NTT_THREADS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, (size_t)4 * NTT_THREADS * NL * 4, st>>>(B);
+#endif
+        }
     } else {
         if ((size_t)A.cols * S > (size_t)NTT_LDS_ELEMS) return hipErrorInvalidValue; // the double tile exists in the fused kernel only
         ntt_pass_kernel<FLAGS><<<dim3(blocks, A.batch ? A.batch : 1), NTT_THREADS, lds, st>>>(A);

@@ -328,3 +328,24 @@ def test_environment_variable_table_is_generated_from_the_sources():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_env_table.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr or r.stdout
+
+
+def test_fault_injection_and_validation_entries_without_a_device():
+    """the testing hooks of include/bbgpu.h are plain host code: a spec is parsed and armed without a device, a bad one is an argument error, the counters start
+    at zero and nothing is alive; bbgpu_srs_set_validate(-1, x) sets the process default, an unknown handle is an argument error"""
+    from barretenberg_amd import BbGpu, BbGpuError
+    lib = BbGpu(init=False)
+    for spec in ("alloc:0", "h2d:17", "d2h:3", "launch:123456789012"):
+        lib.fault_inject(spec)
+        st = lib.fault_stats()
+        assert st["armed"] == 1 and st["fired"] == 0 and st["alloc_calls"] == st["h2d_calls"] == st["d2h_calls"] == st["launch_checks"] == 0
+    for bad in ("alloc", "alloc:", "alloc:x", "free:1", "launch:1:2", ":3"):
+        with pytest.raises(BbGpuError, match="not understood"):
+            lib.fault_inject(bad)
+    lib.fault_inject(None)
+    st = lib.fault_stats()
+    assert st["armed"] == 0 and st["live_allocations"] == 0 and st["live_bytes"] == 0 and st["slots_pending"] == 0
+    lib.srs_set_validate(-1, True)
+    lib.srs_set_validate(-1, False)
+    with pytest.raises(BbGpuError):
+        lib.srs_set_validate(5, True)
