@@ -845,6 +845,36 @@ bool contents_match_full(const SrsEntry& e, size_t off, const uint64_t* points, 
     return job.bad.load() == 0;
 }
 
+// The same check in the BACKGROUND (the staging pool's helper threads alone) for a call whose scalars do not cross the link through that pool (uploads above
+// host_stage_max go to hipMemcpyAsync as they are): started before the upload, joined when the call's kernels have been issued -- the hash of a 2^20-point table
+// (64 MiB of host memory) then runs beside the 32 MiB upload and the launches instead of after them.
+struct FullCheckJob {
+    const uint64_t* p = nullptr;
+    const uint64_t* h = nullptr;
+    std::atomic<int> bad{ 0 };
+    bool posted = false;
+};
+void full_check_post(FullCheckJob& job, const SrsEntry& e, size_t off, const uint64_t* points, size_t n)
+{
+    job.p = points;
+    job.h = e.row_hash.data() + off;
+    job.bad.store(e.row_hash.size() != e.n ? 1 : 0);
+    job.posted = true;
+    if (job.bad.load()) return;
+    g_copy_pool.post_range(n, [](void* c, size_t lo, size_t hi) {
+        FullCheckJob* j = static_cast<FullCheckJob*>(c);
+        uint64_t diff = 0;
+        for (size_t i = lo; i < hi; i++) diff |= hash_row(j->p + i * 16) ^ j->h[i];
+        if (diff) j->bad.store(1);
+    }, &job);
+}
+bool full_check_join(FullCheckJob& job) // true: contents match
+{
+    g_copy_pool.join();
+    job.posted = false;
+    return job.bad.load() == 0;
+}
+
 // table lookup by host address, VALIDATED by content: returns entry index and point offset, or -1.  An auto-registered table whose
 // address range matches but whose contents do not (the caller freed the table and another landed there, or refilled the buffer) is
 // evicted; an explicitly registered one is merely not served (its handle stays valid for the device-pointer entries; in-place mutation
@@ -945,6 +975,11 @@ int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n
     // verifier.cpp:359-363) is used once and forgotten: caching it by address would both leak device memory per call and
     // serve stale points when the caller's vector is freed and its address reused.  Larger unknown tables are taken to be a
     // long-lived SRS and registered on first sight.
+    // exact cache mode on a table large enough that the scalars bypass the staging pool: the full check starts NOW, on the pool's helper threads, and is joined
+    // once the kernels are issued (every way out of this function joins it first: the job reads the caller's table and the entry's fingerprints)
+    FullCheckJob bg;
+    struct BgGuard { FullCheckJob& j; ~BgGuard() { if (j.posted) (void)full_check_join(j); } } bg_guard{ bg };
+    if (full_check && n * 32 > g_ctx.host_stage_max) full_check_post(bg, g_ctx.srs[idx], off, points, n);
     SrsEntry transient{};
     const bool is_transient = idx < 0 && (plain || n < AUTO_REGISTER_MIN_POINTS);
     const bool tr = trace_srs();
@@ -1039,7 +1074,7 @@ int msm_host_ptrs_once(const uint64_t* scalars, const uint64_t* points, size_t n
     }
     const double q2 = tr ? now_ms() : 0;
     // exact mode: every row of the caller's table against the fingerprints of the resident copy, on the host while the kernels issued above run
-    if (rc == BBGPU_OK && full_check && !contents_match_full(g_ctx.srs[idx], off, points, n)) {
+    if (rc == BBGPU_OK && full_check && !(bg.posted ? full_check_join(bg) : contents_match_full(g_ctx.srs[idx], off, points, n))) {
         for (int k = 0; k < ns; k++) drain_ticket(sl[k]);
         srs_mark_stale(idx);
         *stale = true;

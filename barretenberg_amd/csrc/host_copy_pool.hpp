@@ -19,9 +19,11 @@ namespace host {
 
 class CopyPool {
 public:
+    typedef void (*RangeFn)(void* ctx, size_t lo, size_t hi);
     // memcpy(dst, src, bytes), possibly by several threads; returns when all of it is done
     void copy(void* dst, const void* src, size_t bytes)
     {
+        join();
         const int helpers = bytes >= kMinParallel ? ensure_started() : 0;
         if (helpers == 0) {
             std::memcpy(dst, src, bytes);
@@ -48,11 +50,45 @@ public:
         for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins)
             if (spins > 2000) std::this_thread::yield();
     }
+    // The same job on the HELPERS alone, in the background: post_range() returns at once, join() waits for it.  For work that should run beside
+    // something the calling thread does meanwhile (the full content check of a large cached point table beside the upload of the call's scalars and
+    // the launches, capi.hip).  Without helpers the job runs inside post_range().  copy() / for_range() join a posted job before they start theirs.
+    void post_range(size_t items, RangeFn fn, void* ctx)
+    {
+        join();
+        const int helpers = ensure_started();
+        if (helpers == 0 || items == 0) {
+            if (items) fn(ctx, 0, items);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = fn;
+            ctx_ = ctx;
+            bytes_ = items;
+            part_ = (items + (size_t)helpers - 1) / (size_t)helpers;
+            first_part_ = 1; // helper idx (1-based) takes piece idx - 1
+            pending_ = helpers;
+            posted_ = true;
+            ++generation_;
+        }
+        cv_.notify_all();
+    }
+    void join()
+    {
+        if (!posted_) return;
+        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins)
+            if (spins > 2000) std::this_thread::yield();
+        std::lock_guard<std::mutex> lk(mu_);
+        fn_ = nullptr;
+        first_part_ = 0;
+        posted_ = false;
+    }
     // fn(lo, hi) over disjoint pieces of [0, items), the caller's thread taking the first piece; returns when every piece is done.
     // ctx/fn are plain pointers (no allocation on this path).  Used for the full content check of a cached point table (capi.hip).
-    typedef void (*RangeFn)(void* ctx, size_t lo, size_t hi);
     void for_range(size_t items, size_t min_parallel, RangeFn fn, void* ctx)
     {
+        join();
         const int helpers = items >= min_parallel ? ensure_started() : 0;
         if (helpers == 0) {
             fn(ctx, 0, items);
@@ -78,6 +114,7 @@ public:
     }
     void shutdown()
     {
+        join();
         {
             std::lock_guard<std::mutex> lk(mu_);
             if (!started_) return;
@@ -121,15 +158,16 @@ private:
             size_t bytes, part;
             RangeFn fn;
             void* ctx;
+            size_t first;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return generation_ != seen; });
                 seen = generation_;
                 if (stop_) return;
-                dst = dst_; src = src_; bytes = bytes_; part = part_; fn = fn_; ctx = ctx_;
+                dst = dst_; src = src_; bytes = bytes_; part = part_; fn = fn_; ctx = ctx_; first = first_part_;
             }
             if (fn) {
-                const size_t lo = idx * part;
+                const size_t lo = (idx - first) * part;
                 if (lo < bytes) fn(ctx, lo, std::min(lo + part, bytes));
             } else
             run_part(idx, dst, src, bytes, part);
@@ -146,6 +184,8 @@ private:
     size_t bytes_ = 0, part_ = 0;
     RangeFn fn_ = nullptr; // null: the job is a memcpy of bytes_ bytes in part_-sized pieces; else fn_(ctx_, lo, hi) over [0, bytes_) items
     void* ctx_ = nullptr;
+    size_t first_part_ = 0; // 1 while a posted (helpers-only) job is in flight: helper idx takes piece idx - 1
+    bool posted_ = false;   // touched by the producing thread only
     std::atomic<int> pending_{ 0 };
 };
 

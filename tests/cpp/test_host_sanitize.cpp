@@ -178,6 +178,29 @@ int main()
             CHECK(!memcmp(dst.data(), src.data(), src.size()), "copy after a range job %d", rep);
             if (rep == 4) pool.shutdown();
         }
+        // background jobs (post_range / join): the helpers alone work while the caller does something else; a copy issued meanwhile joins the job first
+        for (int rep = 0; rep < 6; rep++) {
+            const size_t items = 50000 + 1234 * (size_t)rep;
+            std::vector<uint32_t> v(items);
+            unsigned long long want = 0;
+            for (size_t i = 0; i < items; i++) { v[i] = (uint32_t)(i * 40503u + (unsigned)rep); want += v[i]; }
+            ctx.v = v.data();
+            ctx.sum = 0;
+            pool.post_range(items, [](void* c, size_t lo, size_t hi) {
+                Ctx* x = static_cast<Ctx*>(c);
+                unsigned long long s = 0;
+                for (size_t i = lo; i < hi; i++) s += x->v[i];
+                x->sum += s;
+            }, &ctx);
+            if (rep & 1) { // a copy while the job is posted
+                std::vector<unsigned char> src((size_t)1 << 20, (unsigned char)(rep + 3)), dst((size_t)1 << 20, 0);
+                pool.copy(dst.data(), src.data(), src.size());
+                CHECK(!memcmp(dst.data(), src.data(), src.size()), "copy while a background job is posted %d", rep);
+            }
+            pool.join();
+            CHECK(ctx.sum.load() == want, "background range job %d", rep);
+            if (rep == 3) pool.shutdown();
+        }
         ctx.sum = 0;
         const uint32_t few[3] = { 1, 2, 3 };
         ctx.v = few;
