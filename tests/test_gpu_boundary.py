@@ -157,6 +157,31 @@ def test_exact_cache_mode_sees_one_rewritten_point_on_the_very_next_call(gpu, or
         # sub-slices of the (re-uploaded) table are served as before
         want = oracle.msm_affine(aligned_copy(scalars[:5000]), aligned_copy(buf[2 * (at - 100):2 * (at + 4900)]), 5000)
         assert np.array_equal(gpu.pippenger(aligned_copy(scalars[:5000]), buf[2 * (at - 100):], 5000)[:8], want[:8])
+        # a table large enough that the call's scalars bypass the staging pool (2^19 points: 16 MiB): there the full check runs in the BACKGROUND on the pool's
+        # helper threads, from before the upload to after the launches.  Checked against the resident path on fresh registrations of the same contents
+        # (the arithmetic is pinned elsewhere; this pins WHICH contents the call used).
+        big_n = 1 << 19
+        hb, big = gpu.srs_generate(limbs(g["srs_secret_mont"]), big_n + 8, True)
+        gpu.srs_release(hb)
+        big_sc = oracle.random_scalars(SCALAR_SEED + 5, big_n)
+        d_big = torch.from_numpy(big_sc.view(np.int64)).cuda()
+
+        def resident(tab):
+            hh = gpu.srs_register(aligned_copy(tab))
+            gpu.srs_set_validate(hh, False)
+            out = gpu.msm_device(hh, d_big.data_ptr(), big_n)
+            gpu.srs_release(hh)
+            return out
+        bufb = aligned_copy(big[:2 * big_n])
+        want0 = resident(bufb)
+        assert np.array_equal(gpu.pippenger(big_sc, bufb, big_n), want0)      # registered on first sight, exact mode
+        assert np.array_equal(gpu.pippenger(big_sc, bufb, big_n), want0)      # served from the copy, background check passes
+        mid = big_n // 2 + 12345
+        bufb[2 * mid:2 * mid + 2] = big[2 * (big_n + 3):2 * (big_n + 3) + 2]   # ONE point rewritten in the middle
+        want1 = resident(bufb)
+        assert not np.array_equal(want1, want0)
+        assert np.array_equal(gpu.pippenger(big_sc, bufb, big_n), want1)      # the very next call
+        assert np.array_equal(gpu.pippenger(big_sc, bufb, big_n), want1)
         gpu.srs_set_validate(-1, False)
         # per-handle flag on an explicitly registered table
         buf2 = aligned_copy(table[:2 * n])
