@@ -1299,30 +1299,37 @@ __device__ __forceinline__ FqN quad_zero()
 {
     return FqN(fe_zero<Fq>());
 }
-// acc: this lane's coordinate of its quad's partial sum; returns the workgroup's sum in quad 0 of wave 0 (lanes 0..3)
-template <int T = QFOLD_T> __device__ __forceinline__ FqN block_quad_sum(FqN acc, uint32_t* sh /* [T / 64][4][NL] */, uint32_t t)
+// acc: this lane's coordinate of its quad's partial sum; returns the workgroup's sum in quad 0 of wave 0 (lanes 0..3).
+// active (block-uniform): only quads [0, active) hold anything but the point at infinity.  Tree levels that could only add infinities are skipped (round 5:
+// a small MSM without window tables sums bucket sets of 4 .. 32 buckets -- 2 .. 8 points per row -- and used to run all six levels, ~4 us each, on zeros).
+template <int T = QFOLD_T> __device__ __forceinline__ FqN block_quad_sum(FqN acc, uint32_t* sh /* [T / 64][4][NL] */, uint32_t t, uint32_t active = T / 4)
 {
     const uint32_t l = t & 3, lane = t & 63, wave = t >> 6, qd = lane >> 2;
+    const uint32_t in_wave = active > 16 * wave ? min(16u, active - 16 * wave) : 0u; // quads of this wave that hold data (wave-uniform)
     for (uint32_t off = 8; off >= 1; off >>= 1) {
+        if (off >= in_wave) continue; // every partner quad qd + off is empty
         FqN o;
 #pragma unroll
         for (int i = 0; i < NL; i++) o.d[i] = __shfl_down(acc.d[i], off * 4);
         if (qd < off) acc = quad_add(acc, o, l);
     }
     if constexpr (T == 64) return acc; // one wave: the tree above was all of it
+    constexpr uint32_t NW = T / 64;
+    const uint32_t waves = min(NW, (active + 15) / 16); // waves that hold data (block-uniform)
+    if (waves <= 1) return acc;                        // wave 0 has it all
     if (lane < 4) {
 #pragma unroll
         for (int i = 0; i < NL; i++) sh[(wave * 4 + l) * NL + i] = acc.d[i];
     }
     __syncthreads();
     if (wave == 0) {
-        constexpr uint32_t NW = T / 64;
         acc = quad_zero();
         if (qd < NW) {
 #pragma unroll
             for (int i = 0; i < NL; i++) acc.d[i] = sh[(qd * 4 + l) * NL + i];
         }
         for (uint32_t off = NW >> 1; off >= 1; off >>= 1) {
+            if (off >= waves) continue;
             FqN o;
 #pragma unroll
             for (int i = 0; i < NL; i++) o.d[i] = __shfl_down(acc.d[i], off * 4);
@@ -1420,7 +1427,7 @@ __global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_rowcol_quad_kernel(const
         acc = first ? v : quad_add(acc, v, l);
         first = false;
     }
-    acc = block_quad_sum(acc, sh, t);
+    acc = block_quad_sum(acc, sh, t, min(count, (uint32_t)QFOLD_T / 4));
     if (t < 4) {
         uint32_t w[8];
         to_canonical(acc, w);
@@ -1493,7 +1500,7 @@ __global__ void __launch_bounds__(64) TAIL_OCC msm_segsum_quad_kernel(const uint
         acc = first ? v : quad_add(acc, v, l);
         first = false;
     }
-    acc = block_quad_sum<64>(acc, nullptr, t);
+    acc = block_quad_sum<64>(acc, nullptr, t, min(count, 16u));
     if (t < 4) {
         uint32_t w[8];
         to_canonical(acc, w);
@@ -1520,7 +1527,7 @@ __global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_final_quad_kernel(const 
         acc = first ? v : quad_add(acc, v, l);
         first = false;
     }
-    acc = block_quad_sum(acc, sh, t);
+    acc = block_quad_sum(acc, sh, t, min(count, (uint32_t)QFOLD_T / 4));
     if (t < 4) {
         uint32_t w[8];
         to_canonical(m261_to_m256<Fq>(acc), w); // the host finishes in the reference's Montgomery form (store_xyzz_m256, coordinate by coordinate)

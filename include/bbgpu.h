@@ -136,11 +136,13 @@ int bbgpu_srs_register(const uint64_t* points_endo_table, size_t n);
  * against the resident copy; if a single row differs the copy is dropped (a table registered on first sight is evicted, an explicitly registered one
  * stops serving host-pointer calls; its handle stays valid) and the call runs once more on a fresh upload: identical inputs -> identical outputs on
  * the very next call, whatever part of the table was rewritten.  srs_handle -1 sets the default for tables registered from now on (on first sight
- * or explicitly); the environment variable BBGPU_SRS_VALIDATE=full does the same at start-up.  Cost on MI355X + EPYC 9575F (tools/validate_ab.py,
- * profiles/r05_boundary_ab.txt, one box, alternating): bbgpu_msm_g1 at 2^16 points 0.352 -> 0.352 ms (+0.1 %: the check hides behind the kernels), at 2^20
- * points 1.71 -> 2.07 ms (+21 %: 64 MiB of host memory hashed per call, longer than the kernels it runs beside); a batch of three 2^20-point jobs over one
- * table 4.68 -> 4.73 ms (+0.9 %: one check per distinct range).  Above 5 % at the headline size, so the DEFAULT STAYS THE 16-ROW SAMPLE and the residual
- * window described above stays with it; a caller that rewrites live tables in place sets the flag. */
+ * or explicitly); the environment variable BBGPU_SRS_VALIDATE=full does the same at start-up.  A table large enough that the call's scalars bypass the staging
+ * pool (more than 8 MiB of them: 2^18 points) is checked in the BACKGROUND on the pool's helper threads, from before the upload of the scalars to after the launches.
+ * Cost on MI355X + EPYC 9575F (tools/validate_ab.py, profiles/r05_boundary_ab.txt, one box each, alternating): bbgpu_msm_g1 at 2^16 points +0.1 % (0.35 ms either
+ * way); at 2^20 points -- 64 MiB of host memory hashed per call -- +5 ... 11 % by box with the default three helper threads (1.70 -> 1.78 ... 1.87 ms; +21 % before
+ * the check moved to the background), +2.7 % with BBGPU_STAGE_THREADS=7, +0.1 % with 11; a batch of three 2^20-point jobs over one table +0.8 % (one check per
+ * distinct range).  At or above 5 % at the headline size with the default threads, so the DEFAULT STAYS THE 16-ROW SAMPLE and the residual window described above
+ * stays with it; a caller that rewrites live tables in place sets the flag (and gives the pool more threads if it has the cores). */
 int bbgpu_srs_set_validate(int srs_handle, int full);
 /* Registration also builds, on the device, the pre-shifted window tables 2^(c w) * P_i (the reference's
  * generate_pippenger_precompute_table idea, scalar_multiplication.cpp:90-129): W x n x 64 bytes (1 GiB at n = 2^20), so that
