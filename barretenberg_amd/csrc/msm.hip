@@ -1610,6 +1610,11 @@ static uint32_t acc_capacity_lanes()
 // chunk length of K4: one resident wave of workgroups covers the whole entry list (no tail wave), >= MIN_CHUNK entries per lane
 // (small MSMs are latency-bound: a lane's chain of `ch` dependent mixed additions is the critical path, ~5 us each)
 constexpr uint32_t MIN_CHUNK = 8;
+// ... 4 for entry lists so short that even then a fraction of the chip is busy (round 5: 256 points without window tables are 16 K entries = eight workgroups walking
+// eight dependent mixed additions each, 45 us; with chunks of four 23 us for one more level in the merge)
+constexpr uint64_t TINY_ENTRIES = (uint64_t)1 << 16;
+constexpr uint32_t TINY_MIN_CHUNK = 4;
+static uint32_t min_chunk(uint64_t m) { return m <= TINY_ENTRIES ? TINY_MIN_CHUNK : MIN_CHUNK; }
 static uint32_t chunk_len_m(uint64_t m);
 static bool chunk_forced()
 {
@@ -1644,7 +1649,7 @@ static uint32_t chunk_len_m(const uint64_t m)
     uint32_t best = 0;
     double best_cost = 0.0;
     for (uint32_t k = 1; k <= acc_wg_per_cu() && k <= 3; k++) {
-        const uint32_t ch = std::max<uint32_t>(MIN_CHUNK, (uint32_t)((m + per_k * k - 1) / (per_k * k)));
+        const uint32_t ch = std::max<uint32_t>(min_chunk(m), (uint32_t)((m + per_k * k - 1) / (per_k * k)));
         const double cost = ch * step[k - 1];
         if (!best || cost < best_cost) { best = ch; best_cost = cost; }
     }
@@ -1713,7 +1718,7 @@ static MsmCarve carve(const MsmPlan& P, size_t n, size_t nw, size_t ng)
     L.totals = p;      p += al(nw * 8 + 512);                    // totals, bases (nw + 1)
     L.heavy = p;       p += al((ng * P.nb + HEAVY_IDS) * 4 + 256 + (size_t)HEAVY_WGS * RAW_WORDS * 4); // heavy-bucket queue: count, arrival counters, ids, slice sums
     L.sorted = p;      p += al(nw * n * 4);
-    L.chunks_cap = (n * nw + MIN_CHUNK - 1) / MIN_CHUNK + 1;     // upper bound for any chunk length >= MIN_CHUNK
+    L.chunks_cap = (n * nw + min_chunk(n * nw) - 1) / min_chunk(n * nw) + 1; // upper bound for any chunk length >= min_chunk (of the WHOLE list: a share's list is shorter, its chunks no shorter than this)
     L.partials = p;    p += al((ng * P.nb + L.chunks_cap) * RAW_WORDS * 4);
     L.buckets = p;     p += al(ng * P.nb * 128);
     L.arena = p;       p += al(arena_points(P, (uint32_t)ng) * 128); // row sums + column sums
@@ -1988,6 +1993,7 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     const bool tp = (tp_env < 0 ? hint : tp_env != 0) && jobs == 1;
     constexpr uint32_t TP_MIN_CHUNK = 20;
     uint32_t ch = bshare ? chunk_len_m(m_expected) : chunk_len(n, nw);
+    ch = std::max(ch, min_chunk((uint64_t)n * nw)); // the workspace's partial slots are laid out for chunks no shorter than the WHOLE list's minimum (carve: chunks_cap)
     if (tp && ch < TP_MIN_CHUNK && !chunk_forced()) // ... as long as one workgroup per CU is left (a 2-of-17-window share of 2^16 points, 131 k entries: chunks of 20 0.091 ms per step, of 8 0.072)
         ch = std::max(ch, std::min<uint32_t>(TP_MIN_CHUNK, (uint32_t)(m_expected / (acc_capacity_lanes() / acc_wg_per_cu()))));
     // merge: 2^logG lanes per bucket, sized for the expected number of partials per bucket (~ entries / (buckets * ch) + 1);
