@@ -475,8 +475,11 @@ __global__ void __launch_bounds__(SORT_THREADS) sortA_colscan_kernel(uint32_t* _
     if (lane == 63) bintot[(size_t)wl * bins + bin] = incl;
 }
 // per group: exclusive scan of the bin totals -> local bin starts, and the group's entry count (bins <= 1024)
+// solo_bases (a launch with ONE group -- a single MSM against window tables, the common case): there is nothing to add up across groups, so this workgroup
+// writes the bases and the list's end itself and sort_bases_kernel is not launched (round 5: one dependent launch, ~5 us of a small MSM's chain).
 __global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(const uint32_t* __restrict__ bintot, uint32_t* __restrict__ binstart,
-                                                                uint32_t* __restrict__ totals, uint32_t bins)
+                                                                uint32_t* __restrict__ totals, uint32_t bins, uint32_t* __restrict__ solo_bases,
+                                                                uint32_t* __restrict__ solo_gstart_end)
 {
     FRONT_PRIO();
     __shared__ uint32_t part[SORT_THREADS];
@@ -491,7 +494,15 @@ __global__ void __launch_bounds__(SORT_THREADS) sortA_scan_kernel(const uint32_t
         __syncthreads();
     }
     if (t < bins) binstart[(size_t)wl * bins + t] = part[t] - mine;
-    if (t == SORT_THREADS - 1) totals[wl] = part[SORT_THREADS - 1];
+    if (t == SORT_THREADS - 1) {
+        totals[wl] = part[SORT_THREADS - 1];
+        if (solo_bases) { // gridDim.x == 1
+            solo_bases[0] = 0;
+            solo_bases[1] = part[SORT_THREADS - 1];
+            solo_gstart_end[0] = part[SORT_THREADS - 1];
+            solo_gstart_end[1] = 0xffffffffu; // sentinel, as in sort_bases_kernel
+        }
+    }
 }
 // window bases (exclusive prefix of the window totals), M = total number of entries -> gstart[total_buckets]
 __global__ void sort_bases_kernel(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bases, uint32_t* __restrict__ gstart_end, uint32_t nw)
@@ -1957,8 +1968,8 @@ int msm_issue_batch(MsmSlot& S, const uint32_t* d_srs, const uint32_t* d_tab, si
     if (wide) sortA_hist_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
     else sortA_hist_kernel<int16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const int16_t*)digits, signs, histA, P.n, sort_bins, sort_lb, slices, slice_len, (uint32_t)wb, wpg, row_i0, row_i1, blo, bcnt);
     sortA_colscan_kernel<<<dim3((sort_bins + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64), G), SORT_THREADS, 0, st>>>(histA, bintot, sort_bins, slices);
-    sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins);
-    sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
+    sortA_scan_kernel<<<G, SORT_THREADS, 0, st>>>(bintot, binstart, totals, sort_bins, G == 1 ? bases : nullptr, gstart + (size_t)G * P.nb);
+    if (G > 1) sort_bases_kernel<<<1, 64, 0, st>>>(totals, bases, gstart + (size_t)G * P.nb, G);
     static const int staged = [] { const char* e = getenv("BBGPU_SORT_STAGED"); return e ? atoi(e) : 3; }(); // tuning knob: bit 0 pass B, bit 1 pass A
     if ((staged & 2) && (P.n & 7u) == 0) {
         if (wide) sortA_scatter_staged_kernel<uint16_t><<<dim3(slices, G), SORT_THREADS, 0, st>>>((const uint16_t*)digits, signs, histA, binstart, bases, tmp_entries, P.n, sort_bins, sort_lb, slices,
