@@ -47,6 +47,9 @@ using Fr = FrP;
 #define BBGPU_FRONT_PRIO 2
 #endif
 #define FRONT_PRIO() __builtin_amdgcn_s_setprio(BBGPU_FRONT_PRIO)
+#ifndef BBGPU_TAIL_PRIO
+#define BBGPU_TAIL_PRIO 3 // the tail kernels' wave priority (short dependent chains); A/B builds: -DBBGPU_TAIL_PRIO=0 .. 3
+#endif
 constexpr int SCALAR_BITS = 254; // r < 2^254 (fr.hpp:12-15)
 constexpr int MSM_MAX_C = 16;    // largest window without tables (one bucket set per window); digits stored as int16
 // (with tables, one shared bucket set: up to 17-bit windows -> 15 of them at 2^20, digits stored as uint16 magnitude + sign bit; capi.hip picks the width)
@@ -1119,7 +1122,7 @@ __global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_merge_kernel(const u
                                                               uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logG)
 {
     // buckets [bucket_begin, total_buckets): a bucket-range share merges (and later folds) its own buckets only
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t G = 1u << logG, b = bucket_begin + (t >> logG), j = t & (G - 1);
     if (b >= total_buckets) return; // whole groups leave together (groups are aligned inside a wave)
@@ -1160,7 +1163,7 @@ __global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_merge_kernel(const u
 __global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_merge_heavy_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ partials,
                                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t ch, uint32_t* __restrict__ hpart)
 {
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[FOLD_LDS_WORDS];
     __shared__ uint32_t last_flag;
     const uint32_t count = heavy[0];
@@ -1236,7 +1239,7 @@ __device__ __forceinline__ uint32_t insert_one_bit(uint32_t m, uint32_t k)
 __global__ void __launch_bounds__(FOLD_T) TAIL_OCC msm_rowcol_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc,
                                                           uint32_t H, uint32_t L, uint32_t* __restrict__ zero_out, uint32_t zero_words)
 {
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[FOLD_LDS_WORDS];
     const uint32_t g = blockIdx.y, t = threadIdx.x, nb = H * L;
     if (zero_out) { // small MSMs: the export slots (infinity = all zero) are cleared here instead of by a fill launch
@@ -1266,7 +1269,7 @@ __global__ void __launch_bounds__(FOLD_T) TAIL_OCC msm_rowcol_kernel(const uint3
 __global__ void __launch_bounds__(FOLD_T) TAIL_OCC msm_final_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
                                                          uint32_t hbits, uint32_t lbits)
 {
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[FOLD_LDS_WORDS];
     const uint32_t g = blockIdx.y, t = threadIdx.x, job = blockIdx.x;
     const uint32_t H = 1u << hbits, L = 1u << lbits;
@@ -1364,7 +1367,7 @@ __global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_merge_quad_kernel(co
                                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t bucket_begin, uint32_t total_buckets,
                                                                    uint32_t ch, uint32_t MERGE_LIGHT, uint32_t logQ)
 {
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, l = t & 3, quad = t >> 2;
     const uint32_t Q = 1u << logQ, b = bucket_begin + (quad >> logQ), j = quad & (Q - 1);
     if (b >= total_buckets) return; // whole bucket groups leave together (4 Q lanes, aligned inside a wave)
@@ -1421,7 +1424,7 @@ __global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_rowcol_quad_kernel(const
 {
     // rows [r0, r0 + rows) of the H x L bucket matrix (all of them, or a bucket-range share's): blockIdx.x < rows sums row r0 + blockIdx.x,
     // the L blocks after them sum the columns over those rows.  R of the other rows is not written: the caller zeroed it (infinity).
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO); // tail kernels: short dependent chains, see msm_issue()
     __shared__ uint32_t sh[(QFOLD_T / 64) * 4 * NL];
     const uint32_t g = blockIdx.y, t = threadIdx.x, nb = H * L, l = t & 3, quad = t >> 2;
     if (zero_out) { // small MSMs: the export slots (infinity = all zero) are cleared here instead of by a fill launch
@@ -1455,7 +1458,7 @@ constexpr uint32_t ROWCOL_SEG = 4;
 __global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_rowcol_seg_kernel(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ segs, uint32_t H, uint32_t L,
                                                                                                                 uint32_t* __restrict__ zero_out, uint32_t zero_words)
 {
-    __builtin_amdgcn_s_setprio(3); // tail kernels: short dependent chains, see msm_issue()
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO); // tail kernels: short dependent chains, see msm_issue()
     const uint32_t g = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x, nb = H * L;
     if (zero_out) { // the export slots (infinity = all zero) are cleared here instead of by a fill launch
         const uint32_t gid = g * gridDim.x * blockDim.x + t, all = gridDim.y * gridDim.x * blockDim.x;
@@ -1498,7 +1501,7 @@ __global__ void __launch_bounds__(MSM_THREADS) TAIL_OCC msm_rowcol_seg_kernel(co
 }
 __global__ void __launch_bounds__(64) TAIL_OCC msm_segsum_quad_kernel(const uint32_t* __restrict__ segs, uint32_t* __restrict__ R, uint32_t* __restrict__ Cc, uint32_t H, uint32_t L)
 {
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO);
     const uint32_t g = blockIdx.y, t = threadIdx.x, l = t & 3, quad = t >> 2;
     const uint32_t row_lanes = H * (L / ROWCOL_SEG), col_lanes = L * (H / ROWCOL_SEG);
     const bool row = blockIdx.x < H;
@@ -1521,7 +1524,7 @@ __global__ void __launch_bounds__(64) TAIL_OCC msm_segsum_quad_kernel(const uint
 __global__ void __launch_bounds__(QFOLD_T) TAIL_OCC msm_final_quad_kernel(const uint32_t* __restrict__ R, const uint32_t* __restrict__ Cc, uint32_t* __restrict__ out,
                                                                  uint32_t hbits, uint32_t lbits)
 {
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(BBGPU_TAIL_PRIO);
     __shared__ uint32_t sh[(QFOLD_T / 64) * 4 * NL];
     const uint32_t g = blockIdx.y, t = threadIdx.x, job = blockIdx.x, l = t & 3, quad = t >> 2;
     const uint32_t H = 1u << hbits, L = 1u << lbits;
