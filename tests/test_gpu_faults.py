@@ -221,3 +221,35 @@ def test_reference_prover_on_the_shim_survives_every_injected_failure(golden, ki
         assert row["pending"] == 0 and row["mem_same"] == 1, (k, row, [x for x in r.stderr.split("\n") if x.startswith("faults ")][:3])
     assert sum(row["fallbacks_failed_proof"] > 0 for row in rows) >= (3 * sites) // 4  # riding out is the exception (an SRS without its window tables)
     assert rest[-1] == "live_after_shutdown 0 allocations 0 bytes", rest[-1]
+
+
+ENV_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from barretenberg_amd import BbGpu, BbGpuError
+from oracle.pyoracle import Oracle
+from tests.util import NTT_SEED
+O, G = Oracle(), BbGpu(device=0)
+G.set_host_thresholds(0, 0)
+co = O.random_scalars(NTT_SEED, 1 << 10)
+want = O.ntt(co, "fft")
+try:
+    G.ntt(co.copy(), "fft")
+    raise SystemExit("the first call did not fail")
+except BbGpuError as e:
+    assert " -1:" in str(e) and "out of memory" in str(e), e  # what a real refusal of that allocation reports
+st = G.fault_stats()
+assert st["fired"] == 1 and st["armed"] == 0, st
+assert np.array_equal(G.ntt(co.copy(), "fft"), want)
+G.shutdown()
+assert G.fault_stats()["live_allocations"] == 0
+print("env-spec ok")
+"""
+
+
+def test_fail_at_from_the_environment():
+    """BBGPU_FAIL_AT, for programs that cannot call bbgpu_fault_inject (the reference prover on the shim): read once, at the library's first funnel"""
+    env = dict(os.environ, BBGPU_FAIL_AT="alloc:0")
+    r = subprocess.run([sys.executable, "-c", ENV_SCRIPT % {"root": ROOT}], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "env-spec ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
